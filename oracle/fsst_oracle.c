@@ -1,0 +1,382 @@
+/*
+ * oracle/fsst_oracle.c -- CPU restatement (plain C, fp64) of the reference FSST feature path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under heart_sounds_segmentation_amd/ links, loads or calls
+ * this file.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may use it,
+ * and only as the checker / reported baseline, never as the thing shipped or measured as "value".
+ *
+ * PARITY STATUS: **parity unpinned** for the FSST core.  The arithmetic of the reference path lives
+ * in a third-party native dependency that is absent from /root/reference:
+ *     ssq 0.1.0 (py311ha7de7f4_0)  ->  libssq 0.1.0 (hb0f4dca_0)  ->  fftw 3.3.10
+ *     (/root/reference/pixi.lock:4609-4620, :2598-2607, :1072; channel pyproject.toml:26,42)
+ * called at /root/reference/hss/transforms/synchrosqueeze.py:48 and
+ * /root/reference/scripts/visualize_signals.py:14.  The reference README (README.md:5-6) says the
+ * package is MATLAB-Coder-generated C++ of MATLAB's fsst(); this file restates that *published*
+ * algorithm (Signal Processing Toolbox fsst.m: zero-padded hop-1 STFT, derivative window from a
+ * not-a-knot cubic spline, instantaneous-frequency estimate -Im(Vd/V), phase shift to the
+ * "modified STFT", cyclic frequency reassignment by accumarray, one-sided output for real x).
+ * The reference's own tests pin SHAPES only (test/test_dataset.py:56-69: (2000,44) and (2000,)),
+ * so the core is checked against the algorithm's invariants (tests/test_oracle.py), not against
+ * reference numbers.  The wrapper epilogue (synchrosqueeze.py:50-111) IS pinned: the golden
+ * fixtures in tests/golden/ were produced by importing that file in the build container with this
+ * oracle injected as the `ssq` module (tests/golden/make_golden.py).
+ *
+ * Every function cites the reference line or the step of the published algorithm it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define HSS_PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------------------------------
+ * dtwin: derivative of the analysis window.  MATLAB fsst.m (local function dtwin):
+ *     pp = spline(1:n, w);  ppd = derivative of each cubic piece;  Wdt = ppval(ppd, 1:n) * Fs/(2*pi)
+ * spline() with a plain vector is the not-a-knot cubic spline.  The derivative at the knots is the
+ * vector of knot slopes s_i, obtained from the classic slope system (unit spacing h = 1):
+ *     interior:   s_{i-1} + 4 s_i + s_{i+1} = 3 (w_{i+1} - w_{i-1})
+ *     not-a-knot: s_0 + 2 s_1 = (5 d_0 + d_1)/2,  s_{n-1} + 2 s_{n-2} = (5 d_{n-2} + d_{n-3})/2,
+ *                 d_i = w_{i+1} - w_i.
+ * Solved here by dense Gaussian elimination with partial pivoting (clarity over speed: n <= ~1024).
+ * n == 2 -> straight line, n == 3 -> parabola (MATLAB spline's documented degenerate cases).
+ * ---------------------------------------------------------------------------------------------- */
+int hss_oracle_dtwin(const double* w, int n, double fs, double* dw)
+{
+    if (!w || !dw || n < 1) return -1;
+    const double scale = fs / (2.0 * HSS_PI);
+    if (n == 1) { dw[0] = 0.0; return 0; }
+    if (n == 2) { dw[0] = dw[1] = (w[1] - w[0]) * scale; return 0; }
+    if (n == 3) {
+        /* parabola through 3 points at x = 1,2,3: derivative at the knots */
+        const double d0 = w[1] - w[0], d1 = w[2] - w[1];
+        dw[0] = (d0 - 0.5 * (d1 - d0)) * scale;
+        dw[1] = (0.5 * (d0 + d1)) * scale;
+        dw[2] = (d1 + 0.5 * (d1 - d0)) * scale;
+        return 0;
+    }
+    double* A = (double*)calloc((size_t)n * (size_t)n, sizeof(double));
+    double* b = (double*)calloc((size_t)n, sizeof(double));
+    if (!A || !b) { free(A); free(b); return -2; }
+    A[0 * n + 0] = 1.0; A[0 * n + 1] = 2.0;
+    b[0] = (5.0 * (w[1] - w[0]) + (w[2] - w[1])) / 2.0;
+    for (int i = 1; i < n - 1; ++i) {
+        A[i * n + i - 1] = 1.0; A[i * n + i] = 4.0; A[i * n + i + 1] = 1.0;
+        b[i] = 3.0 * (w[i + 1] - w[i - 1]);
+    }
+    A[(n - 1) * n + n - 1] = 1.0; A[(n - 1) * n + n - 2] = 2.0;
+    b[n - 1] = (5.0 * (w[n - 1] - w[n - 2]) + (w[n - 2] - w[n - 3])) / 2.0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c; double best = fabs(A[c * n + c]);
+        const int rmax = (c + 3 < n) ? c + 3 : n;   /* band: only rows c..c+2 can be non-zero */
+        for (int r = c + 1; r < rmax; ++r) if (fabs(A[r * n + c]) > best) { best = fabs(A[r * n + c]); piv = r; }
+        if (best == 0.0) { free(A); free(b); return -3; }
+        if (piv != c) {
+            for (int j = 0; j < n; ++j) { double tmp = A[c * n + j]; A[c * n + j] = A[piv * n + j]; A[piv * n + j] = tmp; }
+            double tb = b[c]; b[c] = b[piv]; b[piv] = tb;
+        }
+        for (int r = c + 1; r < rmax; ++r) {
+            const double f = A[r * n + c] / A[c * n + c];
+            if (f == 0.0) continue;
+            for (int j = c; j < n; ++j) A[r * n + j] -= f * A[c * n + j];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double acc = b[i];
+        for (int j = i + 1; j < n; ++j) acc -= A[i * n + j] * dw[j];
+        dw[i] = acc / A[i * n + i];
+    }
+    for (int i = 0; i < n; ++i) dw[i] *= scale;
+    free(A); free(b);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Length-N DFT of a complex vector (fsst.m: computeDFT(..., nfft = numel(window))).
+ * Power-of-two N: iterative radix-2 decimation-in-time; otherwise the O(N^2) definition.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int n; int pow2; double* cs; int* rev; } dft_plan;
+
+static int dft_plan_init(dft_plan* p, int n)
+{
+    p->n = n; p->pow2 = (n & (n - 1)) == 0; p->cs = NULL; p->rev = NULL;
+    p->cs = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+    if (!p->cs) return -2;
+    for (int j = 0; j < n; ++j) {      /* cs[j] = exp(-2*pi*i*j/n) */
+        const double a = -2.0 * HSS_PI * (double)j / (double)n;
+        p->cs[2 * j] = cos(a); p->cs[2 * j + 1] = sin(a);
+    }
+    if (p->pow2) {
+        p->rev = (int*)malloc(sizeof(int) * (size_t)n);
+        if (!p->rev) return -2;
+        int bits = 0; while ((1 << bits) < n) ++bits;
+        for (int i = 0; i < n; ++i) {
+            int r = 0; for (int bq = 0; bq < bits; ++bq) if (i & (1 << bq)) r |= 1 << (bits - 1 - bq);
+            p->rev[i] = r;
+        }
+    }
+    return 0;
+}
+static void dft_plan_free(dft_plan* p) { free(p->cs); free(p->rev); p->cs = NULL; p->rev = NULL; }
+
+/* in: re/im (length n), out: ore/oim (length n); scratch-free */
+static void dft_exec(const dft_plan* p, const double* re, const double* im, double* ore, double* oim)
+{
+    const int n = p->n;
+    if (!p->pow2) {
+        for (int k = 0; k < n; ++k) {
+            double sr = 0.0, si = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const int idx = (int)(((int64_t)k * j) % n);
+                const double c = p->cs[2 * idx], s = p->cs[2 * idx + 1];
+                sr += re[j] * c - im[j] * s;
+                si += re[j] * s + im[j] * c;
+            }
+            ore[k] = sr; oim[k] = si;
+        }
+        return;
+    }
+    for (int i = 0; i < n; ++i) { ore[p->rev[i]] = re[i]; oim[p->rev[i]] = im[i]; }
+    for (int len = 2; len <= n; len <<= 1) {
+        const int half = len >> 1, step = n / len;
+        for (int base = 0; base < n; base += len) {
+            for (int j = 0; j < half; ++j) {
+                const double c = p->cs[2 * (j * step)], s = p->cs[2 * (j * step) + 1];
+                const int a = base + j, b2 = a + half;
+                const double tr = ore[b2] * c - oim[b2] * s;
+                const double ti = ore[b2] * s + oim[b2] * c;
+                ore[b2] = ore[a] - tr; oim[b2] = oim[a] - ti;
+                ore[a] += tr;          oim[a] += ti;
+            }
+        }
+    }
+}
+
+/* MATLAB mod(a, n) for n > 0: result in [0, n) */
+static double matlab_mod(double a, double n)
+{
+    double r = fmod(a, n);
+    if (r < 0.0) r += n;
+    if (r >= n) r = 0.0;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * hss_oracle_fsst: restates `s, f, t = ssq.fsst(x, fs, window)` (call site synchrosqueeze.py:48),
+ * i.e. MATLAB [sst, f, t] = fsst(x, fs, window) for a real vector x:
+ *   1. nfft = numel(window) = N;  pad x with floor(N/2) zeros in front, N-1-floor(N/2) behind;
+ *   2. frames at hop 1: xin(:, t) = xp(t : t+N-1)           (noverlap = N-1)
+ *   3. V  = DFT_N(window .* xin),  Vd = DFT_N(dtwin(window, fs) .* xin),  two-sided k = 0..N-1
+ *   4. fcorr = -imag(Vd ./ V);  fcorr(~isfinite(fcorr)) = 0;  finst = f_k + fcorr
+ *      f_k = psdfreqvec('npts', N, 'Fs', fs): (fs/N)*k, with f(N/2+1) = fs/2 exactly (N even)
+ *      and f(N) = fs - fs/N
+ *   5. modified STFT: V .* exp(-1i*2*pi*floor(N/2)*(0:N-1)'/N)
+ *   6. reassignSpectrum: rowIdx = 1 + mod(round((finst - fmin)*(N-1)/(fmax - fmin)), N), MATLAB
+ *      round = half away from zero (C round()); time column unchanged; accumarray in ascending
+ *      source order k = 0..N-1
+ *   7. real x: keep rows for the 'half' frequency vector: nf = floor(N/2)+1.
+ * Outputs: s_re/s_im (nf x nx, row-major, [k*nx + t]); f (nf) and t (nx) optional (may be NULL).
+ * `halfdist` optional (nx): per time column, min over ALL N source cells of the distance of the
+ * reassignment coordinate from the nearest rounding tie (x.5).  The parity tests use it to tell
+ * fp32-vs-fp64 rounding flips (a5 in SURVEY.md section 8a) from real errors.
+ * Returns nf (> 0) on success, negative on error.
+ * ---------------------------------------------------------------------------------------------- */
+int hss_oracle_fsst(const double* x, int nx, double fs, const double* w, int N,
+                    double* s_re, double* s_im, double* f, double* t, double* halfdist)
+{
+    if (!x || !w || !s_re || !s_im || nx < 1 || N < 1 || !(fs > 0.0)) return -1;
+    const int m = N / 2;
+    const int nf = N / 2 + 1;
+    int rc = 0;
+    double* dw = (double*)malloc(sizeof(double) * (size_t)N);
+    double* fk = (double*)malloc(sizeof(double) * (size_t)N);
+    double* ez = (double*)malloc(sizeof(double) * 2 * (size_t)N);
+    double* buf = (double*)malloc(sizeof(double) * 8 * (size_t)N);
+    double* xp = (double*)calloc((size_t)nx + (size_t)N, sizeof(double));
+    dft_plan plan; plan.cs = NULL; plan.rev = NULL;
+    if (!dw || !fk || !ez || !buf || !xp) { rc = -2; goto done; }
+    if (dft_plan_init(&plan, N) != 0) { rc = -2; goto done; }
+    if (hss_oracle_dtwin(w, N, fs, dw) != 0) { rc = -3; goto done; }
+
+    {   /* psdfreqvec, two-sided */
+        const double res = fs / (double)N;
+        for (int k = 0; k < N; ++k) fk[k] = res * (double)k;
+        if ((N % 2) == 0) fk[N / 2] = fs / 2.0;
+        if (N > 1) fk[N - 1] = fs - res;
+    }
+    for (int k = 0; k < N; ++k) {
+        const double a = -2.0 * HSS_PI * (double)m * (double)k / (double)N;
+        ez[2 * k] = cos(a); ez[2 * k + 1] = sin(a);
+    }
+    memcpy(xp + m, x, sizeof(double) * (size_t)nx);        /* step 1 */
+    if (f) for (int k = 0; k < nf; ++k) f[k] = fk[k];
+    if (t) for (int j = 0; j < nx; ++j) t[j] = (double)j / fs;
+    memset(s_re, 0, sizeof(double) * (size_t)nf * (size_t)nx);
+    memset(s_im, 0, sizeof(double) * (size_t)nf * (size_t)nx);
+
+    {
+        double* are = buf;         double* aim = buf + N;      /* window .* frame (imag = 0) */
+        double* vre = buf + 2 * N; double* vim = buf + 3 * N;
+        double* bre = buf + 4 * N; double* dre = buf + 5 * N;  /* dwindow .* frame */
+        double* dim_ = buf + 6 * N; double* zero = buf + 7 * N;
+        const double fmin = fk[0], fmax = fk[N - 1];
+        for (int j = 0; j < N; ++j) { aim[j] = 0.0; zero[j] = 0.0; }
+        for (int tt = 0; tt < nx; ++tt) {
+            for (int j = 0; j < N; ++j) { are[j] = w[j] * xp[tt + j]; bre[j] = dw[j] * xp[tt + j]; }
+            dft_exec(&plan, are, aim, vre, vim);           /* step 3 */
+            dft_exec(&plan, bre, zero, dre, dim_);
+            double mind = 0.5;
+            for (int k = 0; k < N; ++k) {                  /* steps 4-6, ascending k */
+                /* imag(Vd/V) by the textbook complex quotient */
+                const double den = vre[k] * vre[k] + vim[k] * vim[k];
+                double fc = -((dim_[k] * vre[k] - dre[k] * vim[k]) / den);
+                if (!isfinite(fc)) fc = 0.0;
+                const double finst = fk[k] + fc;
+                double coord;
+                if (N > 1) coord = (finst - fmin) * (double)(N - 1) / (fmax - fmin);
+                else coord = 0.0;
+                const double r = round(coord);
+                const int row = (int)matlab_mod(r, (double)N);
+                if (halfdist) {
+                    const double fr = fabs(fabs(coord - floor(coord)) - 0.5);
+                    if (fr < mind) mind = fr;
+                }
+                if (row < nf) {
+                    const double mr = vre[k] * ez[2 * k] - vim[k] * ez[2 * k + 1];   /* step 5 */
+                    const double mi = vre[k] * ez[2 * k + 1] + vim[k] * ez[2 * k];
+                    s_re[(size_t)row * nx + tt] += mr;
+                    s_im[(size_t)row * nx + tt] += mi;
+                }
+            }
+            if (halfdist) halfdist[tt] = mind;
+        }
+    }
+    rc = nf;
+done:
+    dft_plan_free(&plan);
+    free(dw); free(fk); free(ez); free(buf); free(xp);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Band selection of FSST._truncate_frequencies (synchrosqueeze.py:91-111): the frequency vector is
+ * a float32 tensor (synchrosqueeze.py:52) compared against the Python scalars, i.e. in float32;
+ * both bounds inclusive.  Returns the number of kept rows, first kept row in *klo (rows are
+ * contiguous because f is increasing).
+ * ---------------------------------------------------------------------------------------------- */
+int hss_oracle_band(int N, double fs, double f_lo, double f_hi, int* klo)
+{
+    const int nf = N / 2 + 1;
+    const double res = fs / (double)N;
+    int first = -1, count = 0;
+    for (int k = 0; k < nf; ++k) {
+        double fkd = res * (double)k;
+        if ((N % 2) == 0 && k == N / 2) fkd = fs / 2.0;
+        const float fk32 = (float)fkd;
+        if (fk32 >= (float)f_lo && fk32 <= (float)f_hi) { if (first < 0) first = k; ++count; }
+    }
+    if (klo) *klo = first < 0 ? 0 : first;
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * hss_oracle_features: the whole reference call FSST.__call__ (synchrosqueeze.py:37-65) for a
+ * batch of float32 windows (each row of `x` is one window of nx samples):
+ *   :48     fsst in double on the promoted input
+ *   :50-51  cast s to complex64
+ *   :56-57  optional truncation to [f_lo, f_hi]                    (has_band)
+ *   :59-60  mode 1 (`abs`): |s| transposed        -> out float32 (nx, K)
+ *   :62-63  mode 2 (`stack`): z-score of real and imag separately with the UNBIASED std over all
+ *           K*nx elements (synchrosqueeze.py:78-85), cat along frequency, transposed
+ *                                                  -> out float32 (nx, 2K)
+ *   :65     mode 0 (raw): complex64 (K, nx) un-transposed -> out as interleaved float32 (K, nx, 2)
+ * Statistics are accumulated in double and rounded to float32 (torch reduces in float32 with a
+ * cascade; the two agree to ~1e-7 relative, far inside the 1e-4 gate).
+ * `halfdist` optional (batch*nx), see hss_oracle_fsst.  nthreads <= 1: serial; else OpenMP over
+ * windows.  Returns 0 on success.
+ * ---------------------------------------------------------------------------------------------- */
+int hss_oracle_features(const float* x, int64_t batch, int nx, double fs, const double* w, int N,
+                        int has_band, double f_lo, double f_hi, int mode,
+                        float* out, double* halfdist, int nthreads)
+{
+    if (!x || !w || !out || batch < 0 || nx < 1 || N < 1 || mode < 0 || mode > 2) return -1;
+    const int nf = N / 2 + 1;
+    int klo = 0, K = nf;
+    if (has_band) K = hss_oracle_band(N, fs, f_lo, f_hi, &klo);
+    const size_t per = (mode == 1) ? (size_t)nx * K : (size_t)nx * K * 2;
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int64_t b = 0; b < batch; ++b) {
+        double* xd = (double*)malloc(sizeof(double) * (size_t)nx);
+        double* sre = (double*)malloc(sizeof(double) * (size_t)nf * nx);
+        double* sim = (double*)malloc(sizeof(double) * (size_t)nf * nx);
+        if (!xd || !sre || !sim) { err = -2; free(xd); free(sre); free(sim); continue; }
+        for (int j = 0; j < nx; ++j) xd[j] = (double)x[(size_t)b * nx + j];
+        const int r = hss_oracle_fsst(xd, nx, fs, w, N, sre, sim, NULL, NULL,
+                                      halfdist ? halfdist + (size_t)b * nx : NULL);
+        if (r < 0) { err = r; free(xd); free(sre); free(sim); continue; }
+        float* o = out + (size_t)b * per;
+        if (mode == 0) {
+            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                o[((size_t)k * nx + j) * 2 + 0] = (float)sre[(size_t)(klo + k) * nx + j];
+                o[((size_t)k * nx + j) * 2 + 1] = (float)sim[(size_t)(klo + k) * nx + j];
+            }
+        } else if (mode == 1) {
+            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                const float re = (float)sre[(size_t)(klo + k) * nx + j];
+                const float im = (float)sim[(size_t)(klo + k) * nx + j];
+                o[(size_t)j * K + k] = hypotf(re, im);
+            }
+        } else {
+            const double cnt = (double)K * (double)nx;
+            double sr = 0.0, si = 0.0;
+            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                sr += (double)(float)sre[(size_t)(klo + k) * nx + j];
+                si += (double)(float)sim[(size_t)(klo + k) * nx + j];
+            }
+            const double mr = sr / cnt, mi = si / cnt;
+            double qr = 0.0, qi = 0.0;
+            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                const double dr = (double)(float)sre[(size_t)(klo + k) * nx + j] - mr;
+                const double di = (double)(float)sim[(size_t)(klo + k) * nx + j] - mi;
+                qr += dr * dr; qi += di * di;
+            }
+            const float mean_r = (float)mr, mean_i = (float)mi;
+            const float std_r = (float)sqrt(qr / (cnt - 1.0)), std_i = (float)sqrt(qi / (cnt - 1.0));
+            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                const float re = (float)sre[(size_t)(klo + k) * nx + j];
+                const float im = (float)sim[(size_t)(klo + k) * nx + j];
+                o[(size_t)j * 2 * K + k] = (re - mean_r) / std_r;
+                o[(size_t)j * 2 * K + K + k] = (im - mean_i) / std_i;
+            }
+        }
+        free(xd); free(sre); free(sim);
+    }
+    return err;
+}
+
+/* hss/moments/__init__.py:16 -- m + (x - m) / k */
+double hss_oracle_update_mean(double m, double x, int64_t k) { return m + (x - m) / (double)k; }
+
+/* hss/moments/__init__.py:35-36 -- delta = x - m; var + delta * (x - (m + delta / k)) */
+double hss_oracle_update_variance(double x, double m, double var, int64_t k)
+{
+    const double delta = x - m;
+    return var + delta * (x - (m + delta / (double)k));
+}
+
+int hss_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
