@@ -1,0 +1,98 @@
+"""ctypes loader of libhssfsst.so (C ABI: include/hssfsst.h).
+
+The shared library is built in-tree by ``build()`` (hipcc --offload-arch=gfx950) and is the only
+compute implementation of this package: if it is missing or fails to load, every entry point raises
+-- there is no Python/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhssfsst.so")
+SRC = os.path.join(_PKG, "csrc", "hssfsst.hip")
+HEADER = os.path.join(os.path.dirname(_PKG), "include", "hssfsst.h")
+
+MODE_RAW, MODE_ABS, MODE_STACK, MODE_STACK_UNNORM = 0, 1, 2, 3
+E_INVAL, E_NODEVICE, E_UNSUPPORTED, E_NOMEM, E_HIP = -1, -2, -3, -4, -5
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/hssfsst.hip for gfx950 into libhssfsst.so (cross-compiles without a GPU)."""
+    deps = [SRC, os.path.join(_PKG, "csrc", "fsst_kernels.hpp"), HEADER]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, SRC]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}): {' '.join(cmd)}\n{res.stdout}")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library; raises RuntimeError when it is absent (no fallback)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only implementation of the FSST "
+                "path (no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or heart_sounds_segmentation_amd._lib.build().")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        c_int, c_dbl, c_i64 = ctypes.c_int, ctypes.c_double, ctypes.c_int64
+        vp, ip = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.hssfsst_plan_create.argtypes = [ctypes.POINTER(vp), c_int, c_int, dp, c_dbl, c_int, c_dbl, c_dbl, c_int]
+        L.hssfsst_plan_create.restype = c_int
+        L.hssfsst_plan_destroy.argtypes = [vp]
+        L.hssfsst_plan_destroy.restype = c_int
+        L.hssfsst_plan_info.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip]
+        L.hssfsst_plan_info.restype = c_int
+        L.hssfsst_exec.argtypes = [vp, vp, c_i64, c_int, c_int, vp, c_int, vp]
+        L.hssfsst_exec.restype = c_int
+        L.hssfsst_plan_set_timing.argtypes = [vp, c_int]
+        L.hssfsst_plan_set_timing.restype = c_int
+        L.hssfsst_plan_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ip]
+        L.hssfsst_plan_timing.restype = c_int
+        L.hssfsst_dtwin.argtypes = [dp, c_int, c_dbl, dp]
+        L.hssfsst_dtwin.restype = c_int
+        L.hssfsst_band.argtypes = [c_int, c_dbl, c_dbl, c_dbl, ip, ip]
+        L.hssfsst_band.restype = c_int
+        L.hssfsst_update_mean.argtypes = [c_dbl, c_dbl, c_i64]
+        L.hssfsst_update_mean.restype = c_dbl
+        L.hssfsst_update_variance.argtypes = [c_dbl, c_dbl, c_dbl, c_i64]
+        L.hssfsst_update_variance.restype = c_dbl
+        L.hssfsst_moments_merge.argtypes = [vp, vp, c_i64, c_int, vp, vp]
+        L.hssfsst_moments_merge.restype = c_int
+        L.hssfsst_device_count.restype = c_int
+        L.hssfsst_version.restype = c_int
+        L.hssfsst_last_error.restype = ctypes.c_char_p
+        _lib = L
+        return _lib
+
+
+def check(rc: int, what: str) -> None:
+    """Status -> exception: bad arguments raise ValueError, everything else RuntimeError (the
+    reference's dataset only catches RuntimeError, hss/datasets/heart_sounds.py:183)."""
+    if rc == 0:
+        return
+    msg = lib().hssfsst_last_error().decode("utf-8", "replace")
+    if rc in (E_INVAL, E_UNSUPPORTED):
+        raise ValueError(f"{what}: {msg} (status {rc})")
+    raise RuntimeError(f"{what}: {msg} (status {rc})")

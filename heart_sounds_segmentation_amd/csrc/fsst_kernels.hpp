@@ -1,0 +1,421 @@
+// fsst_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the FSST feature path.
+//
+// What the path computes (reference boundary: /root/reference/hss/transforms/synchrosqueeze.py:48
+// `ssq.fsst(x, fs, window)` + the epilogue :50-111; algorithm steps as restated in
+// oracle/fsst_oracle.c): for every sample t of a signal, the nwin-point DFT of the zero-padded
+// hop-1 frame under the window w (V) and under the derivative window dw (Vd); the instantaneous
+// frequency coordinate a = k - Im(Vd/V) * nwin/fs; the cyclic scatter S[round(a) mod nwin, t] +=
+// (-1)^k V[k, t]; then band truncation and abs / z-score-stack / raw output.
+//
+// MI355X mapping (not a translation of an FFT-library call pattern):
+//   * one frame per lane, one 64-frame tile per wavefront; the signal tile (+ nwin-1 halo) and the
+//     per-lane scatter accumulators live in LDS, so HBM sees 4 B in and 4*out_floats B out per
+//     sample and nothing else;
+//   * nwin = 32*R.  The first radix-R decimation-in-frequency stage is FOLDED into the window
+//     multiply: class r (bins k = R*j + r) is the 32-point FFT of
+//         y_r[n] = sum_q x[t + n + 32 q] * C_r[n, q],   C_r[n,q] = win[n+32q] * W_R^{rq} * W_nwin^{rn}
+//     with C_r precomputed on the host in fp64 and read through the scalar cache (wave-uniform),
+//     so windowing, the first butterfly stage and its twiddles cost one FMA per (output, q);
+//   * real input => only classes r <= R/2 are transformed.  The self-conjugate classes r = 0 and
+//     r = R/2 carry V and Vd packed in ONE complex FFT (two-for-one, partner bin in the same
+//     class); classes 0 < r < R/2 run one FFT for w and one for dw: bins j < 16 are class r's
+//     one-sided bins, bins j >= 16 are (conjugated) the one-sided bins of class R - r;
+//   * every one-sided source bin k' also feeds its negative-frequency mirror nwin - k' (value
+//     conj, row (nwin - row) mod nwin), which reproduces the reference's two-sided cyclic scatter
+//     exactly, including wrap-around into the kept band;
+//   * the 32-point FFT is a fully unrolled radix-2 DIT in registers, twiddles as constants,
+//     6 FMA-class ops per general butterfly (second output as 2e - first);
+//   * MFMA is deliberately unused: at fp32 the matrix pipe has no rate advantage and the only
+//     dense contraction (the folded first stage) is K <= 16 deep.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+namespace hssfsst {
+
+constexpr int kModeRaw = 0, kModeAbs = 1, kModeStack = 2, kModeStackUnnorm = 3;
+
+struct CoreParams {
+    const float* x;       // [batch][n]
+    float* out;           // per mode, see include/hssfsst.h
+    double* partials;     // [batch][nblk][4] = {sum re, sum re^2, sum im, sum im^2} (STACK only)
+    const float* ctab;    // class-folded window tables, [(R/2+1) classes][32 n][4R]
+    int n;                // samples per signal
+    int klo;              // first kept row
+    int K;                // kept rows
+    int mode;
+    int nblk;             // tiles per signal
+};
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// cos(2*pi*j/32), sin(2*pi*j/32), j = 0..15
+__device__ constexpr float kCos32[16] = {
+    1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+    0.70710678118654757f, 0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f,
+    0.0f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f,
+    -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+__device__ constexpr float kSin32[16] = {
+    0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f,
+    0.70710678118654746f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f,
+    1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f,
+    0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+
+constexpr __host__ __device__ int bitrev5(int n)
+{
+    return ((n & 1) << 4) | ((n & 2) << 2) | (n & 4) | ((n & 8) >> 2) | ((n & 16) >> 4);
+}
+
+// Radix-2 DIT butterfly with twiddle W = exp(-2*pi*i*TW/32): (e, o) -> (e + W o, e - W o).
+template <int TW>
+__device__ __forceinline__ void bfly(float& er, float& ei, float& orr, float& oi)
+{
+    constexpr float c = 0.70710678118654752f;
+    float ar, ai, br, bi;
+    if constexpr (TW == 0) {
+        ar = er + orr; ai = ei + oi; br = er - orr; bi = ei - oi;
+    } else if constexpr (TW == 8) {          // W = -i:  W o = (oi, -or)
+        ar = er + oi; ai = ei - orr; br = er - oi; bi = ei + orr;
+    } else if constexpr (TW == 4) {          // W = (1 - i)/sqrt2:  W o = c (or + oi, oi - or)
+        const float sr = orr + oi, si = oi - orr;
+        ar = fmaf(c, sr, er); ai = fmaf(c, si, ei); br = fmaf(-c, sr, er); bi = fmaf(-c, si, ei);
+    } else if constexpr (TW == 12) {         // W = (-1 - i)/sqrt2: W o = c (oi - or, -(or + oi))
+        const float sr = oi - orr, si = orr + oi;
+        ar = fmaf(c, sr, er); ai = fmaf(-c, si, ei); br = fmaf(-c, sr, er); bi = fmaf(c, si, ei);
+    } else {                                 // W = wr + i wi, wr = cos, wi = -sin
+        constexpr float wr = kCos32[TW], wi = -kSin32[TW];
+        ar = fmaf(orr, wr, fmaf(-oi, wi, er));
+        ai = fmaf(orr, wi, fmaf(oi, wr, ei));
+        br = fmaf(2.0f, er, -ar);
+        bi = fmaf(2.0f, ei, -ai);
+    }
+    er = ar; ei = ai; orr = br; oi = bi;
+}
+
+// In-place 32-point complex FFT (forward, e^{-i...}); input in bit-reversed order, output natural.
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32])
+{
+    static_for<5>([&](auto S) {
+        constexpr int L = 2 << decltype(S)::value;
+        constexpr int H = L / 2;
+        constexpr int STEP = 32 / L;
+        static_for<16>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            constexpr int j = b % H;
+            constexpr int a = (b / H) * L + j;
+            bfly<j * STEP>(re[a], im[a], re[a + H], im[a + H]);
+        });
+    });
+}
+
+// Per-lane scatter context: accumulators live in LDS, column `lane` of a [2K][ACC_LD] array.
+struct Scatter {
+    float* acc;   // points at this lane's column
+    int klo;
+    int K;
+    int ld;       // leading dimension (floats)
+};
+
+// One one-sided source bin k' (0 <= k' <= nwin/2) with V = p + i q, Vd' = u + i v (Vd' already in
+// bin units: the host scales dw by nwin/(2*pi) / (fs/(2*pi)) so that -Im(Vd'/V) is a bin shift).
+// Follows oracle/fsst_oracle.c steps 4-6: shift = -Im(Vd/V), non-finite -> 0, coordinate k'+shift,
+// MATLAB round (half away from zero), cyclic row, value (-1)^k' V; plus the mirror source
+// nwin - k' (coordinate nwin - a, value conj).
+template <int NWIN>
+__device__ __forceinline__ void scatter_source(const Scatter& sc, float kp, float sgn, bool mirror,
+                                               float p, float q, float u, float v)
+{
+    const float den = fmaf(p, p, q * q);
+    const float num = fmaf(u, q, -(v * p));
+    float shift = num * __builtin_amdgcn_rcpf(den);
+    if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;       // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
+    const float a = kp + shift;
+    const float r = truncf(a + copysignf(0.5f, a));
+    const int row = static_cast<int>(r) & (NWIN - 1);
+    const float re = sgn * p, im = sgn * q;
+    const int idx = row - sc.klo;
+    if (static_cast<unsigned>(idx) < static_cast<unsigned>(sc.K)) {
+        sc.acc[idx * sc.ld] += re;
+        sc.acc[(sc.K + idx) * sc.ld] += im;
+    }
+    if (mirror) {
+        const int idm = ((NWIN - row) & (NWIN - 1)) - sc.klo;
+        if (static_cast<unsigned>(idm) < static_cast<unsigned>(sc.K)) {
+            sc.acc[idm * sc.ld] += re;
+            sc.acc[(sc.K + idm) * sc.ld] -= im;
+        }
+    }
+}
+
+// Self-conjugate class (r = 0 or r = R/2): V and Vd packed in one complex FFT.
+//   table row (class, n): [re(q=0..R-1) | im(q=0..R-1)] of 0.5*(w + i dw')[n+32q] * phase
+template <int R, bool HALF>
+__device__ __forceinline__ void packed_class(const float* __restrict__ tab, const float* xs,
+                                             const Scatter& sc)
+{
+    constexpr int NWIN = 32 * R;
+    float zr[32], zi[32];
+    static_for<32>([&](auto NN) {
+        constexpr int n = decltype(NN)::value;
+        const float* c = tab + n * 4 * R;
+        float sr = 0.0f, si = 0.0f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const float xv = xs[n + 32 * q];
+            sr = fmaf(xv, c[q], sr);
+            si = fmaf(xv, c[R + q], si);
+        }
+        zr[bitrev5(n)] = sr;
+        zi[bitrev5(n)] = si;
+    });
+    fft32(zr, zi);
+    constexpr int NPRIM = HALF ? 16 : 17;
+    static_for<NPRIM>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value;
+        constexpr int jp = HALF ? (31 - j) : ((32 - j) & 31);
+        constexpr int kp = R * j + (HALF ? R / 2 : 0);
+        const float p = zr[j] + zr[jp];
+        const float q = zi[j] - zi[jp];
+        const float u = zi[j] + zi[jp];
+        const float v = zr[jp] - zr[j];
+        scatter_source<NWIN>(sc, static_cast<float>(kp), (kp & 1) ? -1.0f : 1.0f,
+                             kp != 0 && kp != NWIN / 2, p, q, u, v);
+    });
+}
+
+// Class pair (r, R - r), 0 < r < R/2: one FFT of the w-branch, one of the dw-branch.
+//   table row (class, n): [w re | w im | dw re | dw im], each R wide
+template <int R>
+__device__ __forceinline__ void pair_class(const float* __restrict__ tab, int r, const float* xs,
+                                           const Scatter& sc)
+{
+    constexpr int NWIN = 32 * R;
+    float ar[32], ai[32], dr[32], di[32];
+    static_for<32>([&](auto NN) {
+        constexpr int n = decltype(NN)::value;
+        const float* c = tab + n * 4 * R;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const float xv = xs[n + 32 * q];
+            s0 = fmaf(xv, c[q], s0);
+            s1 = fmaf(xv, c[R + q], s1);
+            s2 = fmaf(xv, c[2 * R + q], s2);
+            s3 = fmaf(xv, c[3 * R + q], s3);
+        }
+        ar[bitrev5(n)] = s0; ai[bitrev5(n)] = s1; dr[bitrev5(n)] = s2; di[bitrev5(n)] = s3;
+    });
+    fft32(ar, ai);
+    fft32(dr, di);
+    const float sgn = (r & 1) ? -1.0f : 1.0f;            // (-1)^(R j + r) = (-1)^r (R even here)
+    static_for<32>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value;
+        if constexpr (j < 16) {                          // k' = R j + r
+            scatter_source<NWIN>(sc, static_cast<float>(R * j) + static_cast<float>(r), sgn, true,
+                                 ar[j], ai[j], dr[j], di[j]);
+        } else {                                         // k' = nwin - (R j + r), conjugated
+            scatter_source<NWIN>(sc, static_cast<float>(NWIN - R * j) - static_cast<float>(r), sgn,
+                                 true, ar[j], -ai[j], dr[j], -di[j]);
+        }
+    });
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Core kernel: one block = one TILE-sample stretch of one signal; one lane = one hop-1 frame.
+// LDS: xs[TILE + nwin - 1 (+pad)] | acc[2K][TILE + 1] | red[4 * TILE/64] doubles (aliases xs).
+// ------------------------------------------------------------------------------------------------
+template <int R, int TILE>
+__global__ __launch_bounds__(TILE) void fsst_core_kernel(CoreParams p)
+{
+    constexpr int NWIN = 32 * R;
+    constexpr int XS = ((TILE + NWIN - 1 + 3) / 4) * 4;
+    constexpr int LD = TILE + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* acc = smem + XS;
+
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x % p.nblk;
+    const long long b = blockIdx.x / p.nblk;
+    const int t0 = blk * TILE;
+    const int n = p.n;
+    const int K = p.K;
+    const float* xsig = p.x + b * static_cast<long long>(n);
+
+    // stage the zero-padded signal tile: xs[i] = xpad[t0 + i] = x[t0 + i - nwin/2]
+    for (int i = tid; i < TILE + NWIN - 1; i += TILE) {
+        const int g = t0 + i - NWIN / 2;
+        xs[i] = (g >= 0 && g < n) ? xsig[g] : 0.0f;
+    }
+    for (int c = 0; c < 2 * K; ++c) acc[c * LD + tid] = 0.0f;
+    __syncthreads();
+
+    Scatter sc{acc + tid, p.klo, K, LD};
+    const float* myx = xs + tid;
+    packed_class<R, false>(p.ctab, myx, sc);
+    if constexpr (R >= 2) packed_class<R, true>(p.ctab + (R / 2) * 32 * 4 * R, myx, sc);
+    if constexpr (R >= 4) {
+        for (int r = 1; r < R / 2; ++r) pair_class<R>(p.ctab + r * 32 * 4 * R, r, myx, sc);
+    }
+    __syncthreads();
+
+    const int valid = min(TILE, n - t0);
+    if (p.mode == kModeRaw) {
+        // complex64 [K][n], frequency-major: lane tid owns sample t0 + tid
+        if (tid < valid) {
+            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(n) + t0 + tid;
+            for (int k = 0; k < K; ++k)
+                dst[static_cast<long long>(k) * n] = make_float2(acc[k * LD + tid], acc[(K + k) * LD + tid]);
+        }
+        return;
+    }
+    // time-major outputs: the tile's block of `valid * C` floats is contiguous in HBM
+    const int C = (p.mode == kModeAbs) ? K : 2 * K;
+    float* dst = p.out + (b * static_cast<long long>(n) + t0) * C;
+    const int total = valid * C;
+    int tt = tid / C, c = tid - tt * C;
+    const int dtt = TILE / C, dc = TILE - dtt * C;
+    float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
+    for (int e = tid; e < total; e += TILE) {
+        float val;
+        if (p.mode == kModeAbs) {
+            const float re = acc[c * LD + tt], im = acc[(K + c) * LD + tt];
+            val = sqrtf(fmaf(re, re, im * im));
+        } else {
+            val = acc[c * LD + tt];
+            if (c < K) { s_re += val; q_re = fmaf(val, val, q_re); }
+            else       { s_im += val; q_im = fmaf(val, val, q_im); }
+        }
+        dst[e] = val;
+        c += dc; tt += dtt;
+        if (c >= C) { c -= C; ++tt; }
+    }
+    if (p.mode != kModeStack) return;
+
+    // per-tile statistics partials in fp64 (fixed reduction order => run-to-run deterministic)
+    double v0 = wave_sum(static_cast<double>(s_re)), v1 = wave_sum(static_cast<double>(q_re));
+    double v2 = wave_sum(static_cast<double>(s_im)), v3 = wave_sum(static_cast<double>(q_im));
+    double* part = p.partials + (b * p.nblk + blk) * 4;
+    if constexpr (TILE == 64) {
+        if (tid == 0) { part[0] = v0; part[1] = v1; part[2] = v2; part[3] = v3; }
+    } else {
+        __syncthreads();                                  // everyone is done reading acc/xs
+        double* red = reinterpret_cast<double*>(smem);    // XS >= 4*(TILE/64) doubles always holds
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) { red[wv * 4 + 0] = v0; red[wv * 4 + 1] = v1; red[wv * 4 + 2] = v2; red[wv * 4 + 3] = v3; }
+        __syncthreads();
+        if (tid < 4) {
+            double s = 0.0;
+            for (int w2 = 0; w2 < TILE / 64; ++w2) s += red[w2 * 4 + tid];
+            part[tid] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STACK epilogue, second half of FSST._stack_real_imag (synchrosqueeze.py:78-85): per signal mean
+// and UNBIASED std of the real block and of the imag block over all K*n elements, then
+// (v - mean) / std in float32, in place.  Streams the signal's n*2K floats once (L2/MALL-warm).
+// grid = (chunks, batch), block = 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const double* partials,
+                                                             int nblk, int n, int K)
+{
+    __shared__ float stat[4];   // mean_re, std_re, mean_im, std_im
+    const long long b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < 2) {
+        const double* part = partials + b * nblk * 4 + tid * 2;
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < nblk; ++i) { s += part[i * 4]; q += part[i * 4 + 1]; }
+        const double cnt = static_cast<double>(K) * static_cast<double>(n);
+        const double mean = s / cnt;
+        const double var = (q - s * mean) / (cnt - 1.0);
+        stat[tid * 2] = static_cast<float>(mean);
+        stat[tid * 2 + 1] = static_cast<float>(sqrt(var));
+    }
+    __syncthreads();
+    const float m_re = stat[0], s_re = stat[1], m_im = stat[2], s_im = stat[3];
+    const int C = 2 * K;
+    const long long total = static_cast<long long>(n) * C;
+    float* base = out + b * total;
+    const long long stride = static_cast<long long>(gridDim.x) * 256;
+    if ((C & 3) == 0) {
+        float4* b4 = reinterpret_cast<float4*>(base);
+        const long long tot4 = total >> 2;
+        for (long long i = static_cast<long long>(blockIdx.x) * 256 + tid; i < tot4; i += stride) {
+            float4 v = b4[i];
+            const int c = static_cast<int>((i * 4) % C);
+            v.x = (c + 0 < K) ? (v.x - m_re) / s_re : (v.x - m_im) / s_im;
+            v.y = (c + 1 < K) ? (v.y - m_re) / s_re : (v.y - m_im) / s_im;
+            v.z = (c + 2 < K) ? (v.z - m_re) / s_re : (v.z - m_im) / s_im;
+            v.w = (c + 3 < K) ? (v.w - m_re) / s_re : (v.w - m_im) / s_im;
+            b4[i] = v;
+        }
+    } else {
+        for (long long i = static_cast<long long>(blockIdx.x) * 256 + tid; i < total; i += stride) {
+            const int c = static_cast<int>(i % C);
+            const float v = base[i];
+            base[i] = (c < K) ? (v - m_re) / s_re : (v - m_im) / s_im;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device counterpart of hss.moments (hss/moments/__init__.py:1-36) for feature chunks: per signal,
+// merge the running {count, mean, M2} of the real and imag blocks with a new un-normalised chunk
+// (Chan's pairwise merge == repeated application of update_mean/update_variance, in exact
+// arithmetic).  grid = batch, block = 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsst_moments_merge_kernel(const float* feats, double* state,
+                                                                 int n, int K)
+{
+    __shared__ double red[4][4];
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int C = 2 * K;
+    const long long total = static_cast<long long>(n) * C;
+    const float* base = feats + b * total;
+    double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
+    for (long long i = tid; i < total; i += 256) {
+        const int c = static_cast<int>(i % C);
+        const double v = static_cast<double>(base[i]);
+        if (c < K) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
+    }
+    s0 = wave_sum(s0); q0 = wave_sum(q0); s1 = wave_sum(s1); q1 = wave_sum(q1);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = q0; red[tid >> 6][2] = s1; red[tid >> 6][3] = q1; }
+    __syncthreads();
+    if (tid < 2) {
+        double s = 0, q = 0;
+        for (int w2 = 0; w2 < 4; ++w2) { s += red[w2][tid * 2]; q += red[w2][tid * 2 + 1]; }
+        const double nb = static_cast<double>(K) * static_cast<double>(n);
+        const double mean_b = s / nb;
+        const double m2_b = q - s * mean_b;
+        double* st = state + b * 6 + tid * 3;
+        const double na = st[0], mean_a = st[1], m2_a = st[2];
+        const double nn = na + nb;
+        const double delta = mean_b - mean_a;
+        st[0] = nn;
+        st[1] = mean_a + delta * (nb / nn);
+        st[2] = m2_a + m2_b + delta * delta * (na * nb / nn);
+    }
+}
+
+}  // namespace hssfsst

@@ -1,0 +1,394 @@
+// hssfsst.hip -- host side of libhssfsst.so: the C ABI declared in include/hssfsst.h.
+// Plan creation does, once and in fp64, everything of the reference's `ssq.fsst(x, fs, window)`
+// (call site /root/reference/hss/transforms/synchrosqueeze.py:48) that depends only on
+// (fs, window); exec launches the gfx950 kernels of fsst_kernels.hpp.
+// There is no CPU compute path here by design (the CPU restatement is oracle/, test-only).
+#include "../../include/hssfsst.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fsst_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(HSSFSST_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// Knot slopes of the not-a-knot cubic spline through (1..n, w): the derivative window of
+// ssq.fsst's instantaneous-frequency estimator before its fs/(2*pi) scaling (MATLAB fsst.m, local
+// function dtwin).  Tridiagonal system (unit spacing):
+//     s0 + 2 s1 = (5 d0 + d1)/2;  s_{i-1} + 4 s_i + s_{i+1} = 3 (w_{i+1} - w_{i-1});
+//     2 s_{n-2} + s_{n-1} = (5 d_{n-2} + d_{n-3})/2,            d_i = w_{i+1} - w_i
+// solved by Gaussian elimination with partial pivoting specialised to tridiagonal matrices
+// (second super-diagonal as fill-in), O(n).
+int spline_knot_slopes(const double* w, int n, double* s)
+{
+    if (n < 1) return HSSFSST_EINVAL;
+    if (n == 1) { s[0] = 0.0; return 0; }
+    if (n == 2) { s[0] = s[1] = w[1] - w[0]; return 0; }
+    if (n == 3) {
+        const double d0 = w[1] - w[0], d1 = w[2] - w[1];
+        s[0] = d0 - 0.5 * (d1 - d0); s[1] = 0.5 * (d0 + d1); s[2] = d1 + 0.5 * (d1 - d0);
+        return 0;
+    }
+    std::vector<double> dl(n, 0.0), d(n, 0.0), du(n, 0.0), du2(n, 0.0), b(n, 0.0);
+    d[0] = 1.0; du[0] = 2.0; b[0] = (5.0 * (w[1] - w[0]) + (w[2] - w[1])) / 2.0;
+    for (int i = 1; i < n - 1; ++i) {
+        dl[i] = 1.0; d[i] = 4.0; du[i] = 1.0; b[i] = 3.0 * (w[i + 1] - w[i - 1]);
+    }
+    dl[n - 1] = 2.0; d[n - 1] = 1.0;
+    b[n - 1] = (5.0 * (w[n - 1] - w[n - 2]) + (w[n - 2] - w[n - 3])) / 2.0;
+    for (int i = 0; i < n - 1; ++i) {            // row i+1 has sub-diagonal dl[i+1]
+        if (std::fabs(d[i]) >= std::fabs(dl[i + 1])) {
+            if (d[i] == 0.0) return HSSFSST_EINVAL;
+            const double f = dl[i + 1] / d[i];
+            d[i + 1] -= f * du[i];
+            if (i + 2 < n) du[i + 1] -= f * du2[i];
+            b[i + 1] -= f * b[i];
+        } else {                                 // swap rows i and i+1
+            const double f = d[i] / dl[i + 1];
+            const double di = dl[i + 1], dui = d[i + 1], du2i = (i + 2 < n) ? du[i + 1] : 0.0;
+            const double bi = b[i + 1];
+            d[i + 1] = du[i] - f * dui;
+            if (i + 2 < n) du[i + 1] = du2[i] - f * du2i;
+            b[i + 1] = b[i] - f * bi;
+            d[i] = di; du[i] = dui; du2[i] = du2i; b[i] = bi;
+        }
+    }
+    if (d[n - 1] == 0.0) return HSSFSST_EINVAL;
+    s[n - 1] = b[n - 1] / d[n - 1];
+    s[n - 2] = (b[n - 2] - du[n - 2] * s[n - 1]) / d[n - 2];
+    for (int i = n - 3; i >= 0; --i) s[i] = (b[i] - du[i] * s[i + 1] - du2[i] * s[i + 2]) / d[i];
+    return 0;
+}
+
+// FSST._truncate_frequencies (synchrosqueeze.py:91-111): f is a float32 tensor (:52) compared
+// with the Python bounds in float32, both inclusive; f_k = k*fs/nwin, Nyquist row = fs/2.
+void band_rows(int nwin, double fs, double f_lo, double f_hi, int* klo, int* K)
+{
+    const int nf = nwin / 2 + 1;
+    const double res = fs / static_cast<double>(nwin);
+    int first = -1, cnt = 0;
+    for (int k = 0; k < nf; ++k) {
+        double fk = res * k;
+        if ((nwin % 2) == 0 && k == nwin / 2) fk = fs / 2.0;
+        const float f32 = static_cast<float>(fk);
+        if (f32 >= static_cast<float>(f_lo) && f32 <= static_cast<float>(f_hi)) {
+            if (first < 0) first = k;
+            ++cnt;
+        }
+    }
+    *klo = first < 0 ? 0 : first;
+    *K = cnt;
+}
+
+constexpr int kTile = 64;
+
+}  // namespace
+
+struct hssfsst_plan {
+    int device = -1;
+    int nwin = 0, R = 0, nf = 0, klo = 0, K = 0, mode = 0;
+    double fs = 0.0;
+    float* d_ctab = nullptr;
+    double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
+    float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
+    float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
+    int timing = 0;
+    std::vector<hipEvent_t> ev;   // 3 per timed exec
+    size_t ev_used = 0;           // events used since timing was enabled
+};
+
+namespace {
+
+int out_floats_per_sample(const hssfsst_plan* p) { return p->mode == HSSFSST_MODE_ABS ? p->K : 2 * p->K; }
+
+template <int R>
+int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long nblocks, hipStream_t st)
+{
+    constexpr int NWIN = 32 * R;
+    constexpr int XS = ((kTile + NWIN - 1 + 3) / 4) * 4;
+    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * pl->K) * (kTile + 1)) * sizeof(float);
+    if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
+    auto kern = hssfsst::fsst_core_kernel<R, kTile>;
+    if (lds > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kTile), lds, st, cp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int grow(void** ptr, size_t* cap, size_t need, size_t elem)
+{
+    if (need <= *cap) return 0;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc(ptr, need * elem);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(HSSFSST_ENOMEM, "hipMalloc(%zu B): %s", need * elem, hipGetErrorString(e)); }
+    *cap = need;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hssfsst_version(void) { return HSSFSST_VERSION; }
+const char* hssfsst_last_error(void) { return g_err; }
+
+int hssfsst_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int hssfsst_dtwin(const double* window, int nwin, double fs, double* dwindow)
+{
+    if (!window || !dwindow || nwin < 1 || !(fs > 0.0)) return fail(HSSFSST_EINVAL, "hssfsst_dtwin: bad argument");
+    const int rc = spline_knot_slopes(window, nwin, dwindow);
+    if (rc != 0) return fail(rc, "hssfsst_dtwin: singular spline system");
+    const double scale = fs / (2.0 * M_PI);
+    for (int i = 0; i < nwin; ++i) dwindow[i] *= scale;
+    return 0;
+}
+
+int hssfsst_band(int nwin, double fs, double f_lo, double f_hi, int* klo, int* K)
+{
+    if (nwin < 1 || !(fs > 0.0) || !klo || !K) return fail(HSSFSST_EINVAL, "hssfsst_band: bad argument");
+    band_rows(nwin, fs, f_lo, f_hi, klo, K);
+    return 0;
+}
+
+double hssfsst_update_mean(double m, double x, int64_t k) { return m + (x - m) / static_cast<double>(k); }
+
+double hssfsst_update_variance(double x, double m, double var, int64_t k)
+{
+    const double delta = x - m;
+    return var + delta * (x - (m + delta / static_cast<double>(k)));
+}
+
+int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* window, double fs,
+                        int has_band, double f_lo, double f_hi, int mode)
+{
+    if (!out) return fail(HSSFSST_EINVAL, "plan_create: out is NULL");
+    *out = nullptr;
+    if (!window || nwin < 1 || !(fs > 0.0) || mode < 0 || mode > HSSFSST_MODE_STACK_UNNORM)
+        return fail(HSSFSST_EINVAL, "plan_create: bad argument (nwin=%d fs=%g mode=%d)", nwin, fs, mode);
+    if (nwin != 32 && nwin != 64 && nwin != 128 && nwin != 256 && nwin != 512)
+        return fail(HSSFSST_EUNSUPPORTED, "plan_create: window length %d not in {32,64,128,256,512}", nwin);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(HSSFSST_ENODEVICE, "plan_create: no HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= ndev) return fail(HSSFSST_EINVAL, "plan_create: device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    hssfsst_plan* p = new (std::nothrow) hssfsst_plan();
+    if (!p) return fail(HSSFSST_ENOMEM, "plan_create: host allocation failed");
+    p->device = device; p->nwin = nwin; p->R = nwin / 32; p->nf = nwin / 2 + 1; p->mode = mode; p->fs = fs;
+    if (has_band) band_rows(nwin, fs, f_lo, f_hi, &p->klo, &p->K);
+    else { p->klo = 0; p->K = p->nf; }
+
+    // derivative window in BIN units: dw * nwin/fs with dw = slope * fs/(2 pi)  =>  slope * nwin/(2 pi)
+    std::vector<double> dwb(nwin);
+    int rc = spline_knot_slopes(window, nwin, dwb.data());
+    if (rc != 0) { delete p; return fail(rc, "plan_create: singular spline system"); }
+    for (int i = 0; i < nwin; ++i) dwb[i] *= static_cast<double>(nwin) / (2.0 * M_PI);
+
+    const int R = p->R;
+    const int ncls = R / 2 + 1;
+    std::vector<float> tab(static_cast<size_t>(ncls) * 32 * 4 * R, 0.0f);
+    for (int r = 0; r < ncls; ++r) {
+        const bool packed = (r == 0) || (2 * r == R);
+        for (int n = 0; n < 32; ++n) {
+            float* row = tab.data() + (static_cast<size_t>(r) * 32 + n) * 4 * R;
+            for (int q = 0; q < R; ++q) {
+                const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / R + static_cast<double>(r) * n / nwin);
+                const double c = std::cos(ang), s = std::sin(ang);
+                const double wv = window[n + 32 * q], dv = dwb[n + 32 * q];
+                if (packed) {            // 0.5 (w + i dw') * phase
+                    row[q] = static_cast<float>(0.5 * (wv * c - dv * s));
+                    row[R + q] = static_cast<float>(0.5 * (wv * s + dv * c));
+                } else {                 // w * phase | dw' * phase
+                    row[q] = static_cast<float>(wv * c);
+                    row[R + q] = static_cast<float>(wv * s);
+                    row[2 * R + q] = static_cast<float>(dv * c);
+                    row[3 * R + q] = static_cast<float>(dv * s);
+                }
+            }
+        }
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&p->d_ctab), tab.size() * sizeof(float));
+    if (e != hipSuccess) { delete p; return fail(HSSFSST_ENOMEM, "plan_create: hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(p->d_ctab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p->d_ctab); delete p; return fail(HSSFSST_EHIP, "plan_create: hipMemcpy: %s", hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+
+int hssfsst_plan_destroy(hssfsst_plan* p)
+{
+    if (!p) return 0;
+    (void)hipSetDevice(p->device);
+    if (p->d_ctab) (void)hipFree(p->d_ctab);
+    if (p->d_partials) (void)hipFree(p->d_partials);
+    if (p->d_xstage) (void)hipFree(p->d_xstage);
+    if (p->d_ostage) (void)hipFree(p->d_ostage);
+    for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
+    delete p;
+    return 0;
+}
+
+int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* K,
+                      int* ofps, int* mode, int* device)
+{
+    if (!p) return fail(HSSFSST_EINVAL, "plan_info: plan is NULL");
+    if (nwin) *nwin = p->nwin;
+    if (nf) *nf = p->nf;
+    if (klo) *klo = p->klo;
+    if (K) *K = p->K;
+    if (ofps) *ofps = out_floats_per_sample(p);
+    if (mode) *mode = p->mode;
+    if (device) *device = p->device;
+    return 0;
+}
+
+int hssfsst_plan_set_timing(hssfsst_plan* p, int enable)
+{
+    if (!p) return fail(HSSFSST_EINVAL, "plan_set_timing: plan is NULL");
+    p->timing = enable ? 1 : 0;
+    p->ev_used = 0;
+    return 0;
+}
+
+int hssfsst_plan_timing(hssfsst_plan* p, float ms_sum[2], int* nexec)
+{
+    if (!p || !ms_sum || !nexec) return fail(HSSFSST_EINVAL, "plan_timing: bad argument");
+    ms_sum[0] = ms_sum[1] = 0.0f;
+    *nexec = static_cast<int>(p->ev_used / 3);
+    if (p->ev_used == 0) return 0;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev[p->ev_used - 1]));
+    for (size_t i = 0; i + 2 < p->ev_used; i += 3) {
+        float a = 0.0f, b = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&a, p->ev[i], p->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, p->ev[i + 1], p->ev[i + 2]));
+        ms_sum[0] += a; ms_sum[1] += b;
+    }
+    return 0;
+}
+
+int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on_device,
+                 float* out, int out_on_device, void* stream)
+{
+    if (!p || !x || !out || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d)", static_cast<long long>(batch), n);
+    if (batch == 0 || p->K == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(p->device));
+    const int ofps = out_floats_per_sample(p);
+    const int nblk = (n + kTile - 1) / kTile;
+    const long long nblocks = static_cast<long long>(batch) * nblk;
+    if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
+    const size_t nx = static_cast<size_t>(batch) * n, no = nx * ofps;
+
+    const float* dx = x;
+    float* dout = out;
+    int rc;
+    if (!x_on_device) {
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_xstage), &p->xstage_cap, nx, sizeof(float))) != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_xstage, x, nx * sizeof(float), hipMemcpyHostToDevice, st));
+        dx = p->d_xstage;
+    }
+    if (!out_on_device) {
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_ostage), &p->ostage_cap, no, sizeof(float))) != 0) return rc;
+        dout = p->d_ostage;
+    }
+    if (p->mode == HSSFSST_MODE_STACK)
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * 4, sizeof(double))) != 0) return rc;
+
+    hssfsst::CoreParams cp;
+    cp.x = dx; cp.out = dout; cp.partials = p->d_partials; cp.ctab = p->d_ctab;
+    cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk;
+
+    hipEvent_t* tev = nullptr;
+    if (p->timing) {
+        while (p->ev.size() < p->ev_used + 3) {
+            hipEvent_t e2 = nullptr;
+            HIP_TRY(hipEventCreate(&e2));
+            p->ev.push_back(e2);
+        }
+        tev = p->ev.data() + p->ev_used;
+        HIP_TRY(hipEventRecord(tev[0], st));
+    }
+    switch (p->R) {
+        case 1: rc = launch_core<1>(p, cp, nblocks, st); break;
+        case 2: rc = launch_core<2>(p, cp, nblocks, st); break;
+        case 4: rc = launch_core<4>(p, cp, nblocks, st); break;
+        case 8: rc = launch_core<8>(p, cp, nblocks, st); break;
+        case 16: rc = launch_core<16>(p, cp, nblocks, st); break;
+        default: rc = fail(HSSFSST_EUNSUPPORTED, "exec: unsupported radix %d", p->R);
+    }
+    if (rc != 0) return rc;
+    if (tev) HIP_TRY(hipEventRecord(tev[1], st));
+    if (p->mode == HSSFSST_MODE_STACK) {
+        const long long per = static_cast<long long>(n) * ofps;
+        long long chunks = (per / 4 + 255) / 256;
+        if (chunks > 16) chunks = 16;
+        if (chunks < 1) chunks = 1;
+        for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+            const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
+            hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(nb)),
+                               dim3(256), 0, st, dout + b0 * per, p->d_partials + b0 * nblk * 4, nblk, n, p->K);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (tev) { HIP_TRY(hipEventRecord(tev[2], st)); p->ev_used += 3; }
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (!x_on_device) {
+        HIP_TRY(hipStreamSynchronize(st));   // the host source may be reused by the caller
+    }
+    return 0;
+}
+
+int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, int n, double* state, void* stream)
+{
+    if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "moments_merge: bad argument");
+    if (batch == 0 || p->K == 0) return 0;
+    if (batch > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "moments_merge: batch too large");
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), feats, state, n, p->K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

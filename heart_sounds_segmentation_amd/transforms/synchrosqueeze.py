@@ -1,0 +1,232 @@
+"""``FSST`` -- drop-in for the reference's ``hss.transforms.FSST``
+(/root/reference/hss/transforms/synchrosqueeze.py:8-111) backed by the gfx950 HIP kernels behind
+the C ABI of ``include/hssfsst.h``.
+
+Same constructor, attribute names, call signature, output shapes / dtypes / orientation and error
+behaviour as the reference class; the body (native ``ssq.fsst`` + torch epilogue) is replaced by one
+``hssfsst_exec`` call.  Extensions that the reference does not have: ``device=`` and ``batch()``.
+There is no CPU implementation here: without the HIP library or a GPU every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+import numpy.typing as npt
+import torch
+
+from .. import _lib
+
+
+class _Plan:
+    """Owner of one ``hssfsst_plan*`` (created lazily in the calling process: fork-safe)."""
+
+    def __init__(self, device_index: int, window: np.ndarray, fs: float, band, mode: int):
+        L = _lib.lib()
+        self._L = L
+        self.handle = ctypes.c_void_p()
+        w = np.ascontiguousarray(window, dtype=np.float64).ravel()
+        has_band = 1 if band else 0
+        lo, hi = (float(band[0]), float(band[1])) if band else (0.0, 0.0)
+        rc = L.hssfsst_plan_create(ctypes.byref(self.handle), int(device_index), int(w.size),
+                                   w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(fs),
+                                   has_band, lo, hi, int(mode))
+        _lib.check(rc, "hssfsst_plan_create")
+        vals = [ctypes.c_int() for _ in range(7)]
+        _lib.check(L.hssfsst_plan_info(self.handle, *[ctypes.byref(v) for v in vals]), "hssfsst_plan_info")
+        self.nwin, self.nf, self.klo, self.K, self.ofps, self.mode, self.device = [v.value for v in vals]
+        self.pid = os.getpid()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value and self.pid == os.getpid():
+                self._L.hssfsst_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class FSST:
+    """
+    Fourier Synchrosqueezed Transform (MI355X / HIP implementation).
+
+    Args mirror the reference constructor (synchrosqueeze.py:13-35):
+        fs: sample frequency.
+        window: analysis window (numpy array); its length is the FFT length.
+        abs: return ``abs(s).t()`` -> float32 ``(n, K)``.
+        stack: return the z-scored real and imaginary parts stacked -> float32 ``(n, 2K)``.
+        truncate_freq: ``(lo, hi)`` in Hz, inclusive; keeps K rows.  None/empty keeps all.
+        dtype: kept for signature parity (the reference only uses it for ``f``/``t``).
+        device (extension): torch device for the computation; default ``cuda`` (current device).
+    Precedence as in ``__call__`` (synchrosqueeze.py:56-65): truncate, then ``abs`` wins over
+    ``stack``, else the raw complex64 ``(K, n)`` spectrum.
+    """
+
+    def __init__(
+        self,
+        fs: float,
+        window: npt.NDArray,
+        abs: bool = False,
+        stack: bool = False,
+        truncate_freq: Optional[tuple] = None,
+        dtype: torch.dtype = torch.float32,
+        device: Optional[torch.device] = None,
+    ):
+        self.fs: float = fs
+        self.window: npt.NDArray = window
+        self.abs = abs
+        self.stack = stack
+        self.truncate_freq = truncate_freq
+        self.dtype = dtype
+        self.device = device
+        self._plans = {}
+
+    # ------------------------------------------------------------------ plan / geometry
+    def _mode(self) -> int:
+        if self.abs:
+            return _lib.MODE_ABS
+        if self.stack:
+            return _lib.MODE_STACK
+        return _lib.MODE_RAW
+
+    def _device_index(self, like: Optional[torch.Tensor] = None) -> int:
+        if like is not None and like.is_cuda:
+            return like.device.index if like.device.index is not None else torch.cuda.current_device()
+        if not torch.cuda.is_available():
+            raise RuntimeError("FSST: no HIP device visible (torch.cuda.is_available() is False); "
+                               "this implementation has no CPU fallback")
+        if self.device is not None:
+            d = torch.device(self.device)
+            if d.type != "cuda":
+                raise RuntimeError(f"FSST: device {d} is not a HIP device; there is no CPU path")
+            return d.index if d.index is not None else torch.cuda.current_device()
+        return torch.cuda.current_device()
+
+    def _plan(self, device_index: int, mode: Optional[int] = None) -> _Plan:
+        mode = self._mode() if mode is None else mode
+        key = (os.getpid(), device_index, mode)
+        plan = self._plans.get(key)
+        if plan is None:
+            band = tuple(self.truncate_freq) if self.truncate_freq else None
+            plan = _Plan(device_index, np.asarray(self.window), float(self.fs), band, mode)
+            self._plans[key] = plan
+        return plan
+
+    def __getstate__(self):          # plans hold device handles: never pickle them into workers
+        st = self.__dict__.copy()
+        st["_plans"] = {}
+        return st
+
+    def band(self):
+        """(klo, K): first kept row and number of kept rows (host-side; no GPU needed)."""
+        klo, K = ctypes.c_int(), ctypes.c_int()
+        w = np.asarray(self.window)
+        if self.truncate_freq:
+            _lib.check(_lib.lib().hssfsst_band(int(w.size), float(self.fs), float(self.truncate_freq[0]),
+                                               float(self.truncate_freq[1]), ctypes.byref(klo),
+                                               ctypes.byref(K)), "hssfsst_band")
+            return klo.value, K.value
+        return 0, int(w.size) // 2 + 1
+
+    # ------------------------------------------------------------------ execution
+    def _run(self, X: torch.Tensor, mode: Optional[int] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """X: (B, n) float32 contiguous, CPU or cuda.  Returns per-mode tensor on X's device."""
+        B, n = X.shape
+        if n < 1:
+            raise ValueError("FSST: empty signal")
+        dev = self._device_index(X)
+        plan = self._plan(dev, mode)
+        K = plan.K
+        m = plan.mode
+        on_dev = X.is_cuda
+        odev = X.device
+        if m == _lib.MODE_RAW:
+            shape, dt = (B, K, n), torch.complex64
+        elif m == _lib.MODE_ABS:
+            shape, dt = (B, n, K), torch.float32
+        else:
+            shape, dt = (B, n, 2 * K), torch.float32
+        if out is None:
+            out = torch.empty(shape, dtype=dt, device=odev)
+        elif (tuple(out.shape) != shape or out.dtype != dt or out.device != odev
+              or not out.is_contiguous()):
+            raise ValueError(f"FSST: out must be a contiguous {dt} tensor of shape {shape} on {odev}")
+        if B == 0 or K == 0:
+            return out
+        stream = torch.cuda.current_stream(dev).cuda_stream if on_dev else None
+        rc = _lib.lib().hssfsst_exec(plan.handle, ctypes.c_void_p(X.data_ptr()), int(B), int(n),
+                                     1 if on_dev else 0, ctypes.c_void_p(out.data_ptr()),
+                                     1 if on_dev else 0, ctypes.c_void_p(stream) if stream else None)
+        _lib.check(rc, "hssfsst_exec")
+        return out
+
+    @staticmethod
+    def _as_f32(x: torch.Tensor) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x))
+        if x.is_complex():
+            raise ValueError("FSST: real input expected")
+        return x.detach().to(torch.float32).contiguous()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """
+        Computes the transform of ONE signal, like the reference ``__call__``
+        (synchrosqueeze.py:37-65).  Accepts what the reference's callers pass: ``(n,)`` or ``(n, 1)``
+        float32 (dataset frames, heart_sounds.py:167,181) or float64 (visualisation script).
+        A CPU tensor returns a CPU tensor, a cuda tensor (extension) stays on the device.
+
+        Returns: ``stack`` -> float32 ``(n, 2K)``; ``abs`` -> float32 ``(n, K)``; otherwise
+        complex64 ``(K, n)``.
+        """
+        x = self._as_f32(x)
+        if x.ndim == 2 and 1 in x.shape:
+            x = x.reshape(-1)
+        if x.ndim != 1:
+            raise ValueError(f"FSST: expected a single signal of shape (n,) or (n, 1), got "
+                             f"{tuple(x.shape)}; use FSST.batch for (B, n)")
+        return self._run(x.unsqueeze(0))[0]
+
+    def batch(self, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Extension: transform ``B`` independent signals at once.  ``X``: ``(B, n)`` (CPU or cuda).
+        Returns ``(B, n, 2K)`` / ``(B, n, K)`` / complex64 ``(B, K, n)`` on X's device; a CPU input
+        is staged through the device by the library.  ``out`` optionally receives the result."""
+        X = self._as_f32(X)
+        if X.ndim == 3 and X.shape[-1] == 1:
+            X = X[..., 0]
+        if X.ndim != 2:
+            raise ValueError(f"FSST.batch: expected (B, n), got {tuple(X.shape)}")
+        return self._run(X, out=out)
+
+    def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
+        """Extension (bench): record HIP events around the kernels of every following call."""
+        dev = self._device_index() if device_index is None else device_index
+        _lib.check(_lib.lib().hssfsst_plan_set_timing(self._plan(dev).handle, 1 if enable else 0),
+                   "hssfsst_plan_set_timing")
+
+    def timing(self, device_index: Optional[int] = None):
+        """(core_ms_sum, normalize_ms_sum, n_calls) since ``set_timing(True)``; synchronises."""
+        dev = self._device_index() if device_index is None else device_index
+        ms = (ctypes.c_float * 2)()
+        cnt = ctypes.c_int()
+        _lib.check(_lib.lib().hssfsst_plan_timing(self._plan(dev).handle, ms, ctypes.byref(cnt)),
+                   "hssfsst_plan_timing")
+        return float(ms[0]), float(ms[1]), cnt.value
+
+    def unnormalized(self, X: torch.Tensor) -> torch.Tensor:
+        """Extension (streaming): ``(B, n, 2K)`` [real | imag] features
+        WITHOUT the per-signal z-score, for use with running moments."""
+        X = self._as_f32(X)
+        if X.ndim == 1:
+            X = X.unsqueeze(0)
+        return self._run(X, _lib.MODE_STACK_UNNORM)
+
+    # ------------------------------------------------------------------ reference helper kept for its contract
+    def _truncate_frequencies(self, s: torch.Tensor, f: torch.Tensor):
+        """Same contract as the reference helper (synchrosqueeze.py:91-111): raises ``ValueError``
+        when ``truncate_freq`` is unset; otherwise slices the rows inside the band."""
+        if not self.truncate_freq:
+            raise ValueError(f"truncate_freq must be set, got: {self.truncate_freq}")
+        klo, K = self.band()
+        return s[klo:klo + K, :], f.reshape(-1)[klo:klo + K]

@@ -1,0 +1,107 @@
+/*
+ * hssfsst.h -- C ABI of libhssfsst.so: the MI355X (gfx950) Fourier-synchrosqueezed-transform
+ * feature path.  This is the drop-in boundary for the ONE native dependency of the reference's hot
+ * path: the CPython extension `ssq` (-> libssq -> FFTW) that
+ *     /root/reference/hss/transforms/synchrosqueeze.py:48   s, f, t = ssq.fsst(x.numpy(), fs, window)
+ * binds, plus the tensor epilogue of the same file (:50-111) which the library fuses on the device.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative HSSFSST_E* code and
+ *     never throws; hssfsst_last_error() returns a thread-local message for the last failure;
+ *   - the caller owns every data buffer; a plan is an opaque handle owned by the library;
+ *   - there is NO CPU compute path in this library: creating a plan needs a HIP device and fails
+ *     with HSSFSST_ENODEVICE otherwise (the CPU restatement lives in oracle/, test-only);
+ *   - HIP is touched for the first time inside hssfsst_plan_create(), in the calling process
+ *     (fork-safe for DataLoader workers: create the plan after the fork);
+ *   - hssfsst_exec() enqueues on `stream` (a hipStream_t, NULL = default stream) and returns
+ *     without synchronising when both buffers are device buffers; with a host buffer on either
+ *     side it stages through the plan's device scratch and synchronises before returning;
+ *   - one plan may be used from one host thread at a time.
+ */
+#ifndef HSSFSST_H
+#define HSSFSST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSSFSST_VERSION 100
+
+/* status codes */
+#define HSSFSST_OK 0
+#define HSSFSST_EINVAL (-1)    /* bad argument (NULL, non-positive size, unknown mode ...)        */
+#define HSSFSST_ENODEVICE (-2) /* no usable HIP device / runtime                                  */
+#define HSSFSST_EUNSUPPORTED (-3) /* window length not in {32,64,128,256,512}                     */
+#define HSSFSST_ENOMEM (-4)    /* host or device allocation failed                                */
+#define HSSFSST_EHIP (-5)      /* a HIP call failed (message in hssfsst_last_error)               */
+
+/* output modes == the branches of FSST.__call__ (synchrosqueeze.py:59-65) */
+#define HSSFSST_MODE_RAW 0   /* :65     complex64 (K, n), frequency-major, interleaved re/im      */
+#define HSSFSST_MODE_ABS 1   /* :59-60  float32 (n, K)   = abs(s).t()                             */
+#define HSSFSST_MODE_STACK 2 /* :62-63  float32 (n, 2K)  = z-scored [real | imag], transposed      */
+#define HSSFSST_MODE_STACK_UNNORM 3 /* extension (streaming): as STACK but without the z-score    */
+
+typedef struct hssfsst_plan hssfsst_plan;
+
+/* Replaces FSST.__init__ (synchrosqueeze.py:13-35) + everything of ssq.fsst that depends only on
+ * (fs, window): derivative window (not-a-knot spline), class-folded twiddle tables, the kept band
+ * of _truncate_frequencies (synchrosqueeze.py:91-111; inclusive bounds compared in float32).
+ *   device     HIP device ordinal (>= 0)
+ *   window     nwin doubles (the analysis window; nfft = nwin); nwin in {32,64,128,256,512}
+ *   has_band   0: keep all nwin/2+1 rows; 1: keep rows with f_lo <= k*fs/nwin <= f_hi
+ *   mode       HSSFSST_MODE_* */
+int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* window, double fs,
+                        int has_band, double f_lo, double f_hi, int mode);
+int hssfsst_plan_destroy(hssfsst_plan* plan);
+
+/* Plan geometry: nf = nwin/2+1 one-sided rows, klo = first kept row, K = number of kept rows,
+ * out_floats_per_sample = floats written per input sample (RAW 2K, ABS K, STACK 2K).
+ * Any output pointer may be NULL. */
+int hssfsst_plan_info(const hssfsst_plan* plan, int* nwin, int* nf, int* klo, int* K,
+                      int* out_floats_per_sample, int* mode, int* device);
+
+/* Replaces the call ssq.fsst(x, fs, window) (synchrosqueeze.py:48) AND the epilogue :50-65 for
+ * `batch` independent signals of `n` samples each (x: float32 [batch][n], contiguous).
+ * out: float32, batch * n * out_floats_per_sample elements, laid out per mode (see HSSFSST_MODE_*),
+ * each signal's block contiguous.  x_on_device / out_on_device: 1 = device pointer on the plan's
+ * device, 0 = host pointer.  stream: hipStream_t or NULL. */
+int hssfsst_exec(hssfsst_plan* plan, const float* x, int64_t batch, int n, int x_on_device,
+                 float* out, int out_on_device, void* stream);
+
+/* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
+ * hssfsst_exec records an event triple around its kernels WITHOUT synchronising; enabling resets
+ * the record.  hssfsst_plan_timing() synchronises once and returns, over all execs since enabling:
+ * ms_sum[0] = total synchrosqueeze-core kernel time, ms_sum[1] = total normalisation kernel time
+ * (0 unless STACK), both in milliseconds, and *nexec = number of execs recorded. */
+int hssfsst_plan_set_timing(hssfsst_plan* plan, int enable);
+int hssfsst_plan_timing(hssfsst_plan* plan, float ms_sum[2], int* nexec);
+
+/* Host helper, no device needed: derivative window of ssq.fsst's IF estimator
+ * (dtwin: not-a-knot cubic spline through (1..n, w), analytic derivative at the knots, * fs/2pi). */
+int hssfsst_dtwin(const double* window, int nwin, double fs, double* dwindow);
+
+/* Host helper, no device needed: kept band of _truncate_frequencies (synchrosqueeze.py:91-111). */
+int hssfsst_band(int nwin, double fs, double f_lo, double f_hi, int* klo, int* K);
+
+/* hss.moments (hss/moments/__init__.py:1-36): scalar running mean and Welford M2 update. */
+double hssfsst_update_mean(double m, double x, int64_t k);
+double hssfsst_update_variance(double x, double m, double var, int64_t k);
+
+/* Device-side counterpart of hss.moments for feature batches: merges, per signal, the running
+ * (count, mean, M2) of the real and imaginary feature blocks with the statistics of a new STACK-less
+ * chunk (Chan's pairwise form of the update above).  state: float64 [batch][6] =
+ * {count_re, mean_re, M2_re, count_im, mean_im, M2_im} on the device.  feats: float32
+ * [batch][n][2K] un-normalised [real | imag] features on the device. */
+int hssfsst_moments_merge(hssfsst_plan* plan, const float* feats, int64_t batch, int n,
+                          double* state, void* stream);
+
+int hssfsst_device_count(void);
+int hssfsst_version(void);
+const char* hssfsst_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSSFSST_H */

@@ -1,0 +1,46 @@
+"""Shared parity gate (SURVEY.md section 8d "Parity gate"; BASELINE.json: features within 1e-4 rel).
+
+Per signal:  max|out - ref| <= TOL * max|ref|  and  ||out - ref||_2 <= TOL * ||ref||_2, evaluated on
+the time columns that are NOT rounding-fragile.  A column is fragile when some source cell's
+reassignment coordinate lies within FRAG_EPS of a rounding tie in the fp64 oracle: there an fp32
+core may legitimately send that cell to the neighbouring row (SURVEY section 7 "discontinuous
+rounding").  Fragile columns are counted and bounded, never silently dropped: the gate also fails
+if they exceed FRAG_BUDGET of all columns, and inside them the error must still be explainable by
+a moved cell (|err| bounded by twice the signal's largest feature).
+"""
+import numpy as np
+
+TOL = 1e-4          # the tolerance north_star states (fp32, relative to the signal's max feature)
+FRAG_EPS = 1e-3     # distance from a rounding tie below which a column is "fragile"
+FRAG_BUDGET = 0.03
+
+
+def check(out, ref, halfdist, time_axis, tol=TOL, frag_eps=FRAG_EPS, frag_budget=FRAG_BUDGET, what=""):
+    """out/ref: one signal's features (real or complex ndarray); halfdist: (n,) from the oracle;
+    time_axis: which axis of out is time.  Returns a dict of measurements; raises AssertionError."""
+    out = np.asarray(out)
+    ref = np.asarray(ref)
+    assert out.shape == ref.shape, f"{what}: shape {out.shape} != {ref.shape}"
+    assert out.dtype == ref.dtype, f"{what}: dtype {out.dtype} != {ref.dtype}"
+    o = np.moveaxis(out, time_axis, 0).reshape(out.shape[time_axis], -1)
+    r = np.moveaxis(ref, time_axis, 0).reshape(ref.shape[time_axis], -1)
+    n = o.shape[0]
+    fragile = np.asarray(halfdist) < frag_eps
+    robust = ~fragile
+    scale = float(np.abs(r).max()) if r.size else 0.0
+    err = np.abs(o - r)
+    assert np.isfinite(o[robust]).all() or not np.isfinite(r[robust]).all(), f"{what}: non-finite output"
+    max_err = float(err[robust].max()) if robust.any() and err.shape[1] else 0.0
+    l2 = float(np.linalg.norm((o - r)[robust])) if robust.any() else 0.0
+    l2ref = float(np.linalg.norm(r[robust])) if robust.any() else 0.0
+    nfrag = int(fragile.sum())
+    res = dict(max_err=max_err, scale=scale, rel=max_err / scale if scale else 0.0,
+               rel_l2=l2 / l2ref if l2ref else 0.0, fragile=nfrag, n=n)
+    assert max_err <= tol * scale, f"{what}: max err {max_err:.3e} > {tol:g} * {scale:.3e} ({res})"
+    assert l2 <= tol * l2ref, f"{what}: rel L2 {res['rel_l2']:.3e} > {tol:g} ({res})"
+    assert nfrag <= max(2, frag_budget * n), f"{what}: {nfrag}/{n} fragile columns exceed the budget"
+    if nfrag and err.shape[1]:
+        # a flipped cell moves at most its own magnitude between two rows
+        # a flipped cell moves at most one cell's magnitude (bounded by ~the signal's max) between rows
+        assert float(err[fragile].max()) <= 2.0 * scale, f"{what}: fragile-column error not explainable"
+    return res

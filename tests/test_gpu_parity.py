@@ -1,0 +1,266 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (ctypes) and through
+the FSST drop-in class, against the CPU oracle on the same seeded inputs, against the committed
+golden fixtures, and -- at BASELINE.json's full C2 size -- through size-independent properties.
+Nothing here reads /root/reference."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from heart_sounds_segmentation_amd import FSST, _lib, synth
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KAISER = synth.kaiser_window(128, 0.5)
+BAND = (25, 200)
+
+
+def _mode(abs_, stack):
+    return "abs" if abs_ else ("stack" if stack else "raw")
+
+
+def _time_axis(mode):
+    return 1 if mode == "raw" else 0
+
+
+def _run_and_check(oracle_mod, X, fs, window, band, abs_=False, stack=False, what="", **kw):
+    tf = FSST(fs, window, abs=abs_, stack=stack, truncate_freq=band)
+    got = tf.batch(torch.from_numpy(X).cuda()).cpu().numpy()
+    mode = _mode(abs_, stack)
+    ref, hd = oracle_mod.features(X, fs, window, band, mode, nthreads=8, return_halfdist=True)
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    stats = [parity.check(got[b], ref[b], hd[b], _time_axis(mode), what=f"{what}[{b}]", **kw)
+             for b in range(X.shape[0])]
+    return got, ref, stats
+
+
+def test_library_loaded_and_device():
+    L = _lib.lib()
+    assert L.hssfsst_version() == 100
+    assert L.hssfsst_device_count() >= 1
+
+
+def test_canonical_stack_pcg(oracle_mod):
+    X = synth.pcg_windows(12, 2000)
+    got, ref, stats = _run_and_check(oracle_mod, X, 1000, KAISER, BAND, stack=True, what="pcg")
+    assert got.shape == (12, 2000, 44)                       # test/test_dataset.py:67-69 of the reference
+    assert max(s["rel"] for s in stats) <= parity.TOL
+
+
+def test_canonical_stack_noise(oracle_mod):
+    X = synth.noise_windows(8, 2000)
+    _run_and_check(oracle_mod, X, 1000, KAISER, BAND, stack=True, what="noise")
+
+
+@pytest.mark.parametrize("abs_,stack,band", [(True, False, BAND), (True, True, BAND), (False, False, BAND),
+                                              (False, False, None), (False, True, None), (True, False, None)])
+def test_modes(oracle_mod, abs_, stack, band):
+    X = synth.noise_windows(3, 700, seed=5)
+    got, ref, _ = _run_and_check(oracle_mod, X, 1000, KAISER, band, abs_=abs_, stack=stack, what="modes")
+    K = 22 if band else 65
+    if abs_:
+        assert got.shape == (3, 700, K) and got.dtype == np.float32
+    elif stack:
+        assert got.shape == (3, 700, 2 * K)
+    else:
+        assert got.shape == (3, K, 700) and got.dtype == np.complex64
+
+
+def test_tone_known_answer():
+    x = synth.tone_window(2000, 1000.0, 16, 128)
+    s = FSST(1000, KAISER).batch(torch.from_numpy(x[None]).cuda())[0].cpu().numpy()
+    col = np.abs(s[:, 1000])
+    assert col.argmax() == 16 and col[16] / col.sum() > 0.99
+
+
+def test_reconstruction_identity_full_size():
+    # (S[0] + S[N/2] + 2 sum_{0<k<N/2} S[k]).real / (N w[N/2]) == x, any size
+    X = synth.pcg_windows(64, 2000, seed=3)
+    s = FSST(1000, KAISER).batch(torch.from_numpy(X).cuda())
+    rec = (s[:, 0] + s[:, 64] + 2 * s[:, 1:64].sum(1)).real / (128 * KAISER[64])
+    err = (rec.cpu().numpy() - X)
+    assert np.abs(err).max() <= 2e-5 * max(1.0, np.abs(X).max())
+
+
+@pytest.mark.parametrize("name,fs,band", [("hann128", 1000, BAND), ("kaiser10_128", 1000, BAND),
+                                          ("hann64", 2000, (100, 600)), ("kaiser10_256", 1000, BAND),
+                                          ("hamming32", 500, None), ("kaiser05_512", 4000, BAND)])
+def test_other_windows(oracle_mod, name, fs, band):
+    from scipy.signal import get_window
+    w = {"hann128": get_window("hann", 128, fftbins=False),
+         "kaiser10_128": get_window(("kaiser", 10.0), 128, fftbins=False),
+         "hann64": get_window("hann", 64, fftbins=False),
+         "kaiser10_256": get_window(("kaiser", 10.0), 256, fftbins=False),
+         "hamming32": get_window("hamming", 32, fftbins=False),
+         "kaiser05_512": get_window(("kaiser", 0.5), 512, fftbins=False)}[name]
+    X = synth.noise_windows(2, 900, seed=9)
+    _run_and_check(oracle_mod, X, fs, w, band, stack=True, what=name, frag_budget=0.25)
+    _run_and_check(oracle_mod, X, fs, w, band, what=name + "/raw", frag_budget=0.25)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 127, 128, 129, 191, 300, 2001])
+def test_ragged_lengths(oracle_mod, n):
+    X = synth.noise_windows(3, n, seed=100 + n)
+    _run_and_check(oracle_mod, X, 1000, KAISER, BAND, abs_=True, what=f"n={n}")
+    if n > 1:
+        _run_and_check(oracle_mod, X, 1000, KAISER, BAND, stack=True, what=f"n={n}/stack")
+
+
+def test_whole_recording(oracle_mod):
+    # lazy dataset path: the transform gets a whole recording (heart_sounds.py:175-182)
+    x = synth.recording(35500)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    got = tf(torch.from_numpy(x))
+    assert got.shape == (35500, 44) and got.device.type == "cpu"
+    ref, hd = oracle_mod.features(x[None], 1000, KAISER, BAND, "stack", nthreads=1, return_halfdist=True)
+    parity.check(got.numpy(), ref[0], hd[0], 0, what="recording")
+
+
+def test_golden_fixtures():
+    g = np.load(os.path.join(GOLD, "fsst_wrapper.npz"))
+    for tag in sorted({k.split("__")[0] for k in g.files}):
+        x, y = g[tag + "__x"], g[tag + "__y"]
+        band = g[tag + "__band"]
+        tr = None if np.isnan(band[0]) else (float(band[0]), float(band[1]))
+        tf = FSST(float(g[tag + "__fs"]), g[tag + "__window"], abs=bool(g[tag + "__abs"]),
+                  stack=bool(g[tag + "__stack"]), truncate_freq=tr)
+        got = tf(torch.from_numpy(x))                      # CPU tensor in -> CPU tensor out
+        assert got.device.type == "cpu" and tuple(got.shape) == y.shape, tag
+        got = got.numpy()
+        assert got.dtype == y.dtype, tag
+        scale = np.abs(y).max()
+        err = np.abs(got - y)
+        # golden data carries no tie-distance vector: allow <= 0.5 % of columns to exceed (flips)
+        tax = 1 if np.iscomplexobj(y) else 0
+        colerr = np.moveaxis(err, tax, 0).reshape(err.shape[tax], -1).max(axis=1)
+        bad = (colerr > parity.TOL * scale).sum()
+        assert bad <= max(1, 0.005 * colerr.size), f"{tag}: {bad} columns off, max {colerr.max():.3e} vs scale {scale:.3e}"
+
+
+def test_input_shapes_and_dtypes(oracle_mod):
+    x = synth.pcg_windows(1, 2000, seed=21)[0]
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    a = tf(torch.from_numpy(x))                                   # (n,) float32 (heart_sounds.py:181)
+    b = tf(torch.from_numpy(x).reshape(2000, 1))                  # (n,1) dataset frame (preprocess.py:31,51)
+    c = tf(torch.from_numpy(x.astype(np.float64)))                # float64 (scripts/visualize_signals.py:10)
+    d = tf(torch.from_numpy(x).cuda())                            # extension: stays on device
+    big = torch.from_numpy(np.stack([x, x], 1))[:, 0]             # non-contiguous view
+    e = tf(big)
+    assert a.shape == (2000, 44) and a.dtype == torch.float32 and a.device.type == "cpu"
+    assert d.device.type == "cuda"
+    for other in (b, c, d.cpu(), e):
+        assert torch.equal(a, other)
+    with pytest.raises(ValueError):
+        tf(torch.zeros(4, 5))
+    with pytest.raises(ValueError):
+        FSST(1000, KAISER)._truncate_frequencies(torch.zeros(65, 3), torch.zeros(65))
+
+
+def test_zero_input_matches_reference_nan_behaviour():
+    # all-zero window => S = 0 => stack output NaN (0/0), abs output 0
+    z = torch.zeros(2, 500).cuda()
+    st = FSST(1000, KAISER, truncate_freq=BAND, stack=True).batch(z)
+    ab = FSST(1000, KAISER, truncate_freq=BAND, abs=True).batch(z)
+    assert torch.isnan(st).all() and (ab == 0).all()
+
+
+def test_empty_band_and_empty_batch():
+    tf = FSST(1000, KAISER, truncate_freq=(1.0, 2.0), stack=True)       # no bin in [1, 2] Hz
+    assert tf.batch(torch.zeros(2, 100).cuda()).shape == (2, 100, 0)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    assert tf.batch(torch.zeros(0, 100).cuda()).shape == (0, 100, 44)
+
+
+def test_c_abi_direct_host_buffers(oracle_mod):
+    """Call exactly what a cgo/ctypes binding of include/hssfsst.h would: host pointers in and out."""
+    L = _lib.lib()
+    X = synth.pcg_windows(4, 1000, seed=77)
+    plan = ctypes.c_void_p()
+    w = np.ascontiguousarray(KAISER)
+    rc = L.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                               1000.0, 1, 25.0, 200.0, _lib.MODE_STACK)
+    assert rc == 0, L.hssfsst_last_error()
+    vals = [ctypes.c_int() for _ in range(7)]
+    assert L.hssfsst_plan_info(plan, *[ctypes.byref(v) for v in vals]) == 0
+    assert [v.value for v in vals][:6] == [128, 65, 4, 22, 44, 2]
+    out = np.empty((4, 1000, 44), np.float32)
+    rc = L.hssfsst_exec(plan, X.ctypes.data_as(ctypes.c_void_p), 4, 1000, 0, out.ctypes.data_as(ctypes.c_void_p), 0, None)
+    assert rc == 0, L.hssfsst_last_error()
+    ref, hd = oracle_mod.features(X, 1000, KAISER, BAND, "stack", nthreads=4, return_halfdist=True)
+    for b in range(4):
+        parity.check(out[b], ref[b], hd[b], 0, what=f"cabi[{b}]")
+    assert L.hssfsst_exec(plan, None, 1, 10, 0, out.ctypes.data_as(ctypes.c_void_p), 0, None) == _lib.E_INVAL
+    assert b"bad argument" in L.hssfsst_last_error()
+    assert L.hssfsst_plan_destroy(plan) == 0
+    bad = np.ones(100)
+    rc = L.hssfsst_plan_create(ctypes.byref(plan), 0, 100, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                               1000.0, 0, 0.0, 0.0, 0)
+    assert rc == _lib.E_UNSUPPORTED
+
+
+def test_full_c2_batch_properties(oracle_mod):
+    """BASELINE.json configs[1] at full size (1024 x 2000): properties that need no oracle run,
+    plus the oracle on a sample of windows."""
+    X = synth.pcg_windows(1024, 2000)
+    Xd = torch.from_numpy(X).cuda()
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    a = tf.batch(Xd)
+    assert a.shape == (1024, 2000, 44)
+    b = tf.batch(Xd)
+    assert torch.equal(a, b)                                        # deterministic (no float atomics)
+    c = tf.batch(Xd * 4.0)                                          # z-score is scale-free; x4 is exact in fp32
+    assert torch.equal(a, c)
+    re, im = a[..., :22], a[..., 22:]
+    for blk in (re, im):
+        m = blk.double().mean(dim=(1, 2))
+        s = blk.double().flatten(1).std(dim=1, unbiased=True)
+        assert m.abs().max() < 1e-5 and (s - 1).abs().max() < 1e-5
+    idx = [0, 1, 511, 777, 1023]
+    sub = tf.batch(Xd[idx])                                         # batch independence
+    assert torch.equal(sub, a[idx])
+    ref, hd = oracle_mod.features(X[idx], 1000, KAISER, BAND, "stack", nthreads=5, return_halfdist=True)
+    an = a[idx].cpu().numpy()
+    for i in range(len(idx)):
+        parity.check(an[i], ref[i], hd[i], 0, what=f"c2[{idx[i]}]")
+    # raw spectrum is homogeneous of degree 1 for power-of-two scaling (exact in fp32)
+    raw = FSST(1000, KAISER, truncate_freq=BAND)
+    r1 = raw.batch(Xd[:32])
+    r2 = raw.batch(Xd[:32] * 2.0)
+    assert torch.equal(torch.view_as_real(r1) * 2.0, torch.view_as_real(r2))
+
+
+def test_unnormalized_and_device_moments(oracle_mod):
+    """hss.moments on the device: merging chunk statistics == the scalar recurrences of
+    hss/moments/__init__.py:16,35-36 applied element by element (oracle)."""
+    X = synth.noise_windows(2, 256, seed=31)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    U = tf.unnormalized(torch.from_numpy(X).cuda())
+    assert U.shape == (2, 256, 44)
+    Z = tf.batch(torch.from_numpy(X).cuda())
+    re = U[..., :22]
+    zn = (re - re.mean(dim=(1, 2), keepdim=True)) / re.flatten(1).std(dim=1, unbiased=True)[:, None, None]
+    assert (zn - Z[..., :22]).abs().max() < 1e-4
+    state = torch.zeros(2, 6, dtype=torch.float64, device="cuda")
+    plan = tf._plan(0, _lib.MODE_STACK_UNNORM)
+    L = _lib.lib()
+    for half in (U[:, :128].contiguous(), U[:, 128:].contiguous()):
+        rc = L.hssfsst_moments_merge(plan.handle, ctypes.c_void_p(half.data_ptr()), 2, 128,
+                                     ctypes.c_void_p(state.data_ptr()), None)
+        assert rc == 0
+    torch.cuda.synchronize()
+    st = state.cpu().numpy()
+    Un = U.cpu().numpy().astype(np.float64)
+    for b in range(2):
+        for blk, off in ((Un[b, :, :22], 0), (Un[b, :, 22:], 3)):
+            m, var, k = 0.0, 0.0, 0
+            for v in blk.ravel():
+                k += 1
+                var = oracle_mod.update_variance(v, m, var, k)
+                m = oracle_mod.update_mean(m, v, k)
+            assert st[b, off] == k
+            assert abs(st[b, off + 1] - m) <= 1e-9 * max(1.0, abs(m))
+            assert abs(st[b, off + 2] - var) <= 1e-9 * var
