@@ -1,0 +1,86 @@
+"""CPU tests of the C-ABI shared library: it builds (hipcc cross-compiles gfx950 without a GPU),
+loads, exports every symbol include/hssfsst.h declares, its host-only entry points agree with the
+oracle, and it fails loudly -- never falls back -- when no HIP device exists."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from heart_sounds_segmentation_amd import _lib, synth
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hssfsst.h")
+NO_GPU = not torch.cuda.is_available()
+KAISER = synth.kaiser_window(128, 0.5)
+
+
+def test_every_declared_symbol_is_exported(built_lib):
+    text = open(HEADER).read()
+    names = sorted(set(re.findall(r"\b(hssfsst_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) >= 14, names
+    for n in names:
+        assert hasattr(built_lib, n), f"{n} declared in include/hssfsst.h but not exported"
+    assert built_lib.hssfsst_version() == int(re.search(r"#define HSSFSST_VERSION (\d+)", text).group(1))
+
+
+def test_gfx950_code_object_present(built_lib):
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"fsst_core_kernel" in blob
+
+
+def test_dtwin_matches_oracle(built_lib, oracle_mod):
+    dp = ctypes.POINTER(ctypes.c_double)
+    for n in (4, 32, 100, 128, 512):
+        w = np.ascontiguousarray(np.kaiser(n, 3.0) + 0.05 * np.sin(np.arange(n)))
+        out = np.empty(n)
+        assert built_lib.hssfsst_dtwin(w.ctypes.data_as(dp), n, 1000.0, out.ctypes.data_as(dp)) == 0
+        ref = oracle_mod.dtwin(w, 1000.0)
+        assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert built_lib.hssfsst_dtwin(None, 4, 1000.0, out.ctypes.data_as(dp)) == _lib.E_INVAL
+    assert b"bad argument" in built_lib.hssfsst_last_error()
+
+
+def test_band_matches_oracle(built_lib, oracle_mod):
+    klo, K = ctypes.c_int(), ctypes.c_int()
+    for N, fs, lo, hi in [(128, 1000.0, 25, 200), (128, 1000.0, 0, 500), (64, 2000.0, 100, 600),
+                          (512, 4000.0, 25, 200), (128, 1000.0, 1, 2), (128, 1000.0, 31.25, 31.25)]:
+        assert built_lib.hssfsst_band(N, fs, float(lo), float(hi), ctypes.byref(klo), ctypes.byref(K)) == 0
+        oklo, oK = oracle_mod.band(N, fs, lo, hi)
+        assert K.value == oK and (oK == 0 or klo.value == oklo)
+    built_lib.hssfsst_band(128, 1000.0, 25.0, 200.0, ctypes.byref(klo), ctypes.byref(K))
+    assert (klo.value, K.value) == (4, 22)
+
+
+def test_moments_match_reference_golden(built_lib):
+    from heart_sounds_segmentation_amd import moments
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "moments.npz"))
+    m, var = 0.0, 0.0
+    for k, xv in enumerate(g["xs"], start=1):
+        var = moments.update_variance(float(xv), m, var, k)
+        m = moments.update_mean(m, float(xv), k)
+        assert m == g["means"][k - 1] and var == g["m2s"][k - 1]
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode")
+def test_plan_create_fails_loudly_without_device(built_lib):
+    plan = ctypes.c_void_p()
+    w = np.ascontiguousarray(KAISER)
+    rc = built_lib.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                       1000.0, 1, 25.0, 200.0, 2)
+    assert rc == _lib.E_NODEVICE and not plan.value
+    assert b"no CPU path" in built_lib.hssfsst_last_error()
+    assert built_lib.hssfsst_device_count() == 0
+
+
+def test_argument_validation_needs_no_device(built_lib):
+    plan = ctypes.c_void_p()
+    w = np.ones(100)
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert built_lib.hssfsst_plan_create(ctypes.byref(plan), 0, 100, w.ctypes.data_as(dp), 1000.0, 0, 0.0, 0.0, 0) == _lib.E_UNSUPPORTED
+    assert built_lib.hssfsst_plan_create(ctypes.byref(plan), 0, 128, None, 1000.0, 0, 0.0, 0.0, 0) == _lib.E_INVAL
+    assert built_lib.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(dp), -1.0, 0, 0.0, 0.0, 0) == _lib.E_INVAL
+    assert built_lib.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(dp), 1000.0, 0, 0.0, 0.0, 9) == _lib.E_INVAL
+    assert built_lib.hssfsst_plan_destroy(None) == 0
+    assert built_lib.hssfsst_plan_info(None, None, None, None, None, None, None, None) == _lib.E_INVAL

@@ -1,0 +1,92 @@
+"""CPU tests of the host-side mirror of the reference interface (hss.transforms.FSST,
+hss.moments): constructor / attribute parity, error behaviour, fork/pickle safety, and that the
+product never computes on the CPU."""
+import inspect
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from heart_sounds_segmentation_amd import FSST, synth, transforms
+
+KAISER = synth.kaiser_window(128, 0.5)
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_constructor_signature_matches_reference():
+    # /root/reference/hss/transforms/synchrosqueeze.py:13-21
+    params = list(inspect.signature(FSST.__init__).parameters)
+    assert params[:7] == ["self", "fs", "window", "abs", "stack", "truncate_freq", "dtype"]
+    sig = inspect.signature(FSST.__init__).parameters
+    assert sig["abs"].default is False and sig["stack"].default is False
+    assert sig["truncate_freq"].default is None and sig["dtype"].default is torch.float32
+    tf = FSST(1000, KAISER, truncate_freq=(25, 200), stack=True)
+    assert tf.fs == 1000 and tf.window is KAISER and tf.abs is False and tf.stack is True
+    assert tf.truncate_freq == (25, 200) and tf.dtype is torch.float32
+    assert transforms.__all__ == ["FSST"] and callable(tf)
+
+
+def test_band_geometry_on_host(built_lib):
+    assert FSST(1000, KAISER, truncate_freq=(25, 200)).band() == (4, 22)
+    assert FSST(1000, KAISER).band() == (0, 65)
+    assert FSST(1000, KAISER, truncate_freq=(1, 2)).band()[1] == 0
+
+
+def test_truncate_valueerror_contract(built_lib):
+    with pytest.raises(ValueError, match="truncate_freq must be set"):     # synchrosqueeze.py:104-105
+        FSST(1000, KAISER)._truncate_frequencies(torch.zeros(65, 3), torch.zeros(65))
+    s, f = FSST(1000, KAISER, truncate_freq=(25, 200))._truncate_frequencies(
+        torch.arange(65.0)[:, None].repeat(1, 3), torch.arange(65.0) * 7.8125)
+    assert s.shape == (22, 3) and f[0] == 31.25 and f[-1] == 195.3125
+
+
+def test_pickle_drops_device_handles(built_lib):
+    tf = FSST(1000, KAISER, truncate_freq=(25, 200), stack=True)
+    tf._plans[("fake",)] = object()
+    tf2 = pickle.loads(pickle.dumps(tf))
+    assert tf2._plans == {} and tf2.truncate_freq == (25, 200) and np.array_equal(tf2.window, KAISER)
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode")
+def test_no_cpu_fallback(built_lib):
+    tf = FSST(1000, KAISER, truncate_freq=(25, 200), stack=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tf(torch.zeros(2000))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        FSST(1000, KAISER, device="cpu").batch(torch.zeros(2, 100))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from heart_sounds_segmentation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "heart_sounds_segmentation_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text, fn
+                assert "hss_oracle" not in text, fn
+
+
+def test_frame_signal_golden_contract():
+    """Window set fed to the path (hss/utils/preprocess.py:40-56 semantics pinned by the fixture):
+    L = floor((T-n)/stride) frames, or ONE frame x[:n] when L <= 0."""
+    from heart_sounds_segmentation_amd import framing
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_signal.npz"))
+    for T in (35000, 35500, 4000, 3000, 2500, 2000, 1500):
+        starts, lens = framing.frame_starts(T, 1000, 2000)
+        assert np.array_equal(starts, g[f"T{T}__starts"]), T
+        assert np.array_equal(lens, g[f"T{T}__lens"]), T
+    x = torch.arange(35500, dtype=torch.float32)
+    F = framing.frame_batch(x, 1000, 2000)
+    assert F.shape == (33, 2000) and F[5, 0] == 5000 and F[32, -1] == 33999
