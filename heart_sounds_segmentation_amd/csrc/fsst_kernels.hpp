@@ -48,6 +48,10 @@ struct CoreParams {
     int nblk;             // tiles per signal
 };
 
+// Window tables are read-only for the whole launch and indexed wave-uniformly: the constant
+// address space lets hipcc fetch them with scalar loads (s_load_dwordx*) through the scalar cache.
+using ctab_ptr = const float __attribute__((address_space(4)))*;
+
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f)
 {
@@ -118,56 +122,70 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32])
     });
 }
 
-// Per-lane scatter context: accumulators live in LDS, column `lane` of a [2K][ACC_LD] array.
+// Per-lane scatter context.  Two LDS planes per lane, each a column of a [2K][LD] array:
+//   own  -- written exactly once per kept row k by source k itself (plain store, no RMW):
+//           (-1)^k V[k] if the source stays in its own row, else 0;
+//   disp -- zero-initialised; receives the (rare) displaced sources by read-modify-write.
+// The lane owns its columns, so no atomics and a fixed summation order (deterministic output).
+template <int LD>
 struct Scatter {
-    float* acc;   // points at this lane's column
+    float* own;
+    float* disp;
     int klo;
     int K;
-    int ld;       // leading dimension (floats)
+    __device__ __forceinline__ void add(int row, float re, float im) const
+    {
+        const int idx = row - klo;
+        if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) {
+            disp[idx * LD] += re;
+            disp[(K + idx) * LD] += im;
+        }
+    }
 };
 
 // One one-sided source bin k' (0 <= k' <= nwin/2) with V = p + i q, Vd' = u + i v (Vd' already in
-// bin units: the host scales dw by nwin/(2*pi) / (fs/(2*pi)) so that -Im(Vd'/V) is a bin shift).
-// Follows oracle/fsst_oracle.c steps 4-6: shift = -Im(Vd/V), non-finite -> 0, coordinate k'+shift,
-// MATLAB round (half away from zero), cyclic row, value (-1)^k' V; plus the mirror source
-// nwin - k' (coordinate nwin - a, value conj).
-template <int NWIN>
-__device__ __forceinline__ void scatter_source(const Scatter& sc, float kp, float sgn, bool mirror,
-                                               float p, float q, float u, float v)
+// bin units: the host scales the derivative window by nwin/fs, so -Im(Vd'/V) is a shift in bins).
+// Follows oracle/fsst_oracle.c steps 4-6: shift = -Im(Vd/V) (non-finite -> 0), coordinate
+// a = k' + shift, MATLAB round (half away from zero), cyclic row, value (-1)^k' V; the mirror
+// source nwin - k' has coordinate nwin - a and value conj.
+// Fast path: the source stays in row k' iff |shift| < 1/2 iff |num| < den/2 -- no division; its
+// mirror then lands in row nwin - k' > nwin/2, outside every kept band.  V == 0 contributes 0
+// wherever it lands and is treated as staying.  Only when some lane of the wave has a displaced
+// cell does the wave run the exact rounding path for those lanes.
+template <int NWIN, int LD>
+__device__ __forceinline__ void scatter_source(const Scatter<LD>& sc, float kp, int kpi, float sgn,
+                                               bool mirror, float p, float q, float u, float v)
 {
     const float den = fmaf(p, p, q * q);
     const float num = fmaf(u, q, -(v * p));
-    float shift = num * __builtin_amdgcn_rcpf(den);
-    if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;       // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
-    const float a = kp + shift;
-    const float r = truncf(a + copysignf(0.5f, a));
-    const int row = static_cast<int>(r) & (NWIN - 1);
+    const bool moved = (fabsf(num) >= 0.5f * den) && (den > 0.0f);
     const float re = sgn * p, im = sgn * q;
-    const int idx = row - sc.klo;
-    if (static_cast<unsigned>(idx) < static_cast<unsigned>(sc.K)) {
-        sc.acc[idx * sc.ld] += re;
-        sc.acc[(sc.K + idx) * sc.ld] += im;
+    const int slot = kpi - sc.klo;                        // wave-uniform
+    if (static_cast<unsigned>(slot) < static_cast<unsigned>(sc.K)) {
+        sc.own[slot * LD] = moved ? 0.0f : re;
+        sc.own[(sc.K + slot) * LD] = moved ? 0.0f : im;
     }
-    if (mirror) {
-        const int idm = ((NWIN - row) & (NWIN - 1)) - sc.klo;
-        if (static_cast<unsigned>(idm) < static_cast<unsigned>(sc.K)) {
-            sc.acc[idm * sc.ld] += re;
-            sc.acc[(sc.K + idm) * sc.ld] -= im;
-        }
+    if (moved) {
+        float shift = num * __builtin_amdgcn_rcpf(den);
+        if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;      // inf / absurd -> 0 (fsst.m: ~isfinite)
+        const float a = kp + shift;
+        const float r = truncf(a + copysignf(0.5f, a));
+        const int row = static_cast<int>(r) & (NWIN - 1);
+        sc.add(row, re, im);
+        if (mirror) sc.add((NWIN - row) & (NWIN - 1), re, -im);
     }
 }
 
 // Self-conjugate class (r = 0 or r = R/2): V and Vd packed in one complex FFT.
 //   table row (class, n): [re(q=0..R-1) | im(q=0..R-1)] of 0.5*(w + i dw')[n+32q] * phase
-template <int R, bool HALF>
-__device__ __forceinline__ void packed_class(const float* __restrict__ tab, const float* xs,
-                                             const Scatter& sc)
+template <int R, bool HALF, int LD>
+__device__ __forceinline__ void packed_class(ctab_ptr tab, const float* xs, const Scatter<LD>& sc)
 {
     constexpr int NWIN = 32 * R;
     float zr[32], zi[32];
     static_for<32>([&](auto NN) {
         constexpr int n = decltype(NN)::value;
-        const float* c = tab + n * 4 * R;
+        ctab_ptr c = tab + n * 4 * R;
         float sr = 0.0f, si = 0.0f;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -188,22 +206,21 @@ __device__ __forceinline__ void packed_class(const float* __restrict__ tab, cons
         const float q = zi[j] - zi[jp];
         const float u = zi[j] + zi[jp];
         const float v = zr[jp] - zr[j];
-        scatter_source<NWIN>(sc, static_cast<float>(kp), (kp & 1) ? -1.0f : 1.0f,
-                             kp != 0 && kp != NWIN / 2, p, q, u, v);
+        scatter_source<NWIN, LD>(sc, static_cast<float>(kp), kp, (kp & 1) ? -1.0f : 1.0f,
+                                 kp != 0 && kp != NWIN / 2, p, q, u, v);
     });
 }
 
 // Class pair (r, R - r), 0 < r < R/2: one FFT of the w-branch, one of the dw-branch.
 //   table row (class, n): [w re | w im | dw re | dw im], each R wide
-template <int R>
-__device__ __forceinline__ void pair_class(const float* __restrict__ tab, int r, const float* xs,
-                                           const Scatter& sc)
+template <int R, int LD>
+__device__ __forceinline__ void pair_class(ctab_ptr tab, int r, const float* xs, const Scatter<LD>& sc)
 {
     constexpr int NWIN = 32 * R;
     float ar[32], ai[32], dr[32], di[32];
     static_for<32>([&](auto NN) {
         constexpr int n = decltype(NN)::value;
-        const float* c = tab + n * 4 * R;
+        ctab_ptr c = tab + n * 4 * R;
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -221,11 +238,11 @@ __device__ __forceinline__ void pair_class(const float* __restrict__ tab, int r,
     static_for<32>([&](auto JJ) {
         constexpr int j = decltype(JJ)::value;
         if constexpr (j < 16) {                          // k' = R j + r
-            scatter_source<NWIN>(sc, static_cast<float>(R * j) + static_cast<float>(r), sgn, true,
-                                 ar[j], ai[j], dr[j], di[j]);
+            scatter_source<NWIN, LD>(sc, static_cast<float>(R * j + r), R * j + r, sgn, true,
+                                     ar[j], ai[j], dr[j], di[j]);
         } else {                                         // k' = nwin - (R j + r), conjugated
-            scatter_source<NWIN>(sc, static_cast<float>(NWIN - R * j) - static_cast<float>(r), sgn,
-                                 true, ar[j], -ai[j], dr[j], -di[j]);
+            scatter_source<NWIN, LD>(sc, static_cast<float>(NWIN - R * j - r), NWIN - R * j - r, sgn,
+                                     true, ar[j], -ai[j], dr[j], -di[j]);
         }
     });
 }
@@ -239,7 +256,7 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // ------------------------------------------------------------------------------------------------
 // Core kernel: one block = one TILE-sample stretch of one signal; one lane = one hop-1 frame.
-// LDS: xs[TILE + nwin - 1 (+pad)] | acc[2K][TILE + 1] | red[4 * TILE/64] doubles (aliases xs).
+// LDS: xs[TILE + nwin - 1 (+pad)] | own[2K][TILE + 1] | disp[2K][TILE + 1]; red[] aliases xs.
 // ------------------------------------------------------------------------------------------------
 template <int R, int TILE>
 __global__ __launch_bounds__(TILE) void fsst_core_kernel(CoreParams p)
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(TILE) void fsst_core_kernel(CoreParams p)
     constexpr int LD = TILE + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
-    float* acc = smem + XS;
+    float* own = smem + XS;
 
     const int tid = threadIdx.x;
     const int blk = blockIdx.x % p.nblk;
@@ -264,17 +281,28 @@ __global__ __launch_bounds__(TILE) void fsst_core_kernel(CoreParams p)
         const int g = t0 + i - NWIN / 2;
         xs[i] = (g >= 0 && g < n) ? xsig[g] : 0.0f;
     }
-    for (int c = 0; c < 2 * K; ++c) acc[c * LD + tid] = 0.0f;
+    float* disp = own + 2 * K * LD;
+    for (int c = 0; c < 2 * K; ++c) disp[c * LD + tid] = 0.0f;
     __syncthreads();
 
-    Scatter sc{acc + tid, p.klo, K, LD};
+    const Scatter<LD> sc{own + tid, disp + tid, p.klo, K};
     const float* myx = xs + tid;
-    packed_class<R, false>(p.ctab, myx, sc);
-    if constexpr (R >= 2) packed_class<R, true>(p.ctab + (R / 2) * 32 * 4 * R, myx, sc);
-    if constexpr (R >= 4) {
-        for (int r = 1; r < R / 2; ++r) pair_class<R>(p.ctab + r * 32 * 4 * R, r, myx, sc);
+    ctab_ptr tab = (ctab_ptr)p.ctab;
+    packed_class<R, false, LD>(tab, myx, sc);
+    if constexpr (R >= 2) packed_class<R, true, LD>(tab + (R / 2) * 32 * 4 * R, myx, sc);
+    if constexpr (R >= 4 && R <= 8) {
+        static_for<R / 2 - 1>([&](auto RR) {
+            constexpr int r = decltype(RR)::value + 1;
+            pair_class<R, LD>(tab + r * 32 * 4 * R, r, myx, sc);
+        });
+    } else if constexpr (R > 8) {
+        for (int r = 1; r < R / 2; ++r) pair_class<R, LD>(tab + r * 32 * 4 * R, r, myx, sc);
     }
     __syncthreads();
+    // fold the displaced plane into the own plane (each lane its own column: no hazard)
+    for (int c = 0; c < 2 * K; ++c) own[c * LD + tid] += disp[c * LD + tid];
+    __syncthreads();
+    float* acc = own;
 
     const int valid = min(TILE, n - t0);
     if (p.mode == kModeRaw) {

@@ -131,7 +131,7 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
 {
     constexpr int NWIN = 32 * R;
     constexpr int XS = ((kTile + NWIN - 1 + 3) / 4) * 4;
-    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * pl->K) * (kTile + 1)) * sizeof(float);
+    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(4 * pl->K) * (kTile + 1)) * sizeof(float);
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     auto kern = hssfsst::fsst_core_kernel<R, kTile>;
     if (lds > 32 * 1024)

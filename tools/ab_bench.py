@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B of several builds of libhssfsst.so on the C2 workload.
+usage: ab_bench.py lib_a.so lib_b.so ...   (prints per-build core/normalize kernel ms, median of rounds)"""
+import ctypes
+import sys
+import os
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heart_sounds_segmentation_amd import synth  # noqa: E402
+
+
+def load(path):
+    L = ctypes.CDLL(path)
+    vp, ip, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
+    L.hssfsst_plan_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, dp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    L.hssfsst_exec.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
+    L.hssfsst_plan_set_timing.argtypes = [vp, ctypes.c_int]
+    L.hssfsst_plan_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ip]
+    L.hssfsst_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def main():
+    libs = sys.argv[1:]
+    B = int(os.environ.get("AB_BATCH", "1024"))
+    rounds = int(os.environ.get("AB_ROUNDS", "5"))
+    steps = int(os.environ.get("AB_STEPS", "10"))
+    w = np.ascontiguousarray(synth.kaiser_window(128, 0.5))
+    X = torch.from_numpy(synth.pcg_windows(B, 2000)).cuda()
+    outs, plans, Ls = [], [], []
+    for path in libs:
+        L = load(path)
+        plan = ctypes.c_void_p()
+        rc = L.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1000.0, 1, 25.0, 200.0, 2)
+        assert rc == 0, L.hssfsst_last_error()
+        out = torch.empty((B, 2000, 44), dtype=torch.float32, device="cuda")
+        Ls.append(L); plans.append(plan); outs.append(out)
+    res = {p: [] for p in libs}
+    for rd in range(rounds + 1):
+        for i, path in enumerate(libs):
+            L, plan, out = Ls[i], plans[i], outs[i]
+            L.hssfsst_plan_set_timing(plan, 1)
+            for _ in range(steps):
+                rc = L.hssfsst_exec(plan, ctypes.c_void_p(X.data_ptr()), B, 2000, 1, ctypes.c_void_p(out.data_ptr()), 1, None)
+                assert rc == 0, L.hssfsst_last_error()
+            ms = (ctypes.c_float * 2)(); cnt = ctypes.c_int()
+            L.hssfsst_plan_timing(plan, ms, ctypes.byref(cnt))
+            if rd > 0:
+                res[path].append((ms[0] / cnt.value, ms[1] / cnt.value))
+    ref = outs[0]
+    for i, path in enumerate(libs):
+        a = np.asarray(res[path])
+        diff = (outs[i] - ref).abs().max().item()
+        core, norm = np.median(a[:, 0]), np.median(a[:, 1])
+        print(f"{os.path.basename(path):28s} core {core:8.4f} ms (min {a[:,0].min():.4f})  norm {norm:7.4f} ms  "
+              f"=> {B / ((core + norm) * 1e-3) / 1e6:6.3f} Mwin/s  core-roofline {360000 * B / (core * 1e-3) / 8e12 * 100:5.2f}%  maxdiff_vs_first {diff:.2e}")
+
+
+if __name__ == "__main__":
+    main()
