@@ -259,7 +259,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // LDS: xs[TILE + nwin - 1 (+pad)] | own[2K][TILE + 1] | disp[2K][TILE + 1]; red[] aliases xs.
 // ------------------------------------------------------------------------------------------------
 template <int R, int TILE>
-__global__ __launch_bounds__(TILE) void fsst_core_kernel(CoreParams p)
+__global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
 {
     constexpr int NWIN = 32 * R;
     constexpr int XS = ((TILE + NWIN - 1 + 3) / 4) * 4;

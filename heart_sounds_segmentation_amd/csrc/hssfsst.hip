@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "fsst_kernels.hpp"
+#include "fsst_mfma128.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -106,6 +108,7 @@ void band_rows(int nwin, double fs, double f_lo, double f_hi, int* klo, int* K)
 }
 
 constexpr int kTile = 64;
+constexpr int kFpw128 = 64;      // frames per wave tile of the nwin = 128 kernel
 
 }  // namespace
 
@@ -113,7 +116,8 @@ struct hssfsst_plan {
     int device = -1;
     int nwin = 0, R = 0, nf = 0, klo = 0, K = 0, mode = 0;
     double fs = 0.0;
-    float* d_ctab = nullptr;
+    float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
+    float* d_atab = nullptr;      // nwin == 128: MFMA A-operand constants [32][64]
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
@@ -138,6 +142,22 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kTile), lds, st, cp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, int n, int64_t batch, int nblk, hipStream_t st)
+{
+    constexpr int XS = ((kFpw128 + 127 + 3) / 4) * 4;
+    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * 2 * 16 * hssfsst::plane_ldf(pl->K)) + 72 * 2) * sizeof(float);
+    hssfsst::Core128Params cp;
+    cp.x = dx; cp.out = dout; cp.partials = pl->d_partials; cp.atab = pl->d_atab;
+    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk;
+    auto kern = hssfsst::fsst_core128_kernel<kFpw128>;
+    if (lds > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(batch * nblk)), dim3(64), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -249,6 +269,34 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     if (e != hipSuccess) { delete p; return fail(HSSFSST_ENOMEM, "plan_create: hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(p->d_ctab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(p->d_ctab); delete p; return fail(HSSFSST_EHIP, "plan_create: hipMemcpy: %s", hipGetErrorString(e)); }
+    const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
+    if (nwin == 128 && !(force && force[0] == '1')) {
+        // A[i][k] of v_mfma_f32_16x16x4_f32 for tap n, k-half h: lane l holds row i = l & 15, k = l >> 4.
+        // Row i: lane group gg = i >> 2 owns classes ca = gg and cb = (gg ? 8 - gg : 4); sub = i & 3:
+        // {ca re, ca im, cb re, cb im}.  Entry = component of
+        //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + 16 q] * exp(-2 pi i (r q / 8 + r n / 128)),  q = k + 4 h.
+        std::vector<float> at(32 * 64);
+        for (int n = 0; n < 16; ++n)
+            for (int h = 0; h < 2; ++h)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, q = (l >> 4) + 4 * h;
+                    const int gg = i >> 2, sub = i & 3;
+                    const int r = (sub < 2) ? gg : (gg ? 8 - gg : 4);
+                    const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / 8.0 + static_cast<double>(r) * n / 128.0);
+                    const double c = std::cos(ang), sn = std::sin(ang);
+                    const double sg = (r & 1) ? -0.5 : 0.5;
+                    const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
+                    const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
+                    at[(n * 2 + h) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
+                }
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_atab), at.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (p->d_atab) (void)hipFree(p->d_atab);
+            (void)hipFree(p->d_ctab); delete p;
+            return fail(HSSFSST_EHIP, "plan_create: A-table upload: %s", hipGetErrorString(e));
+        }
+    }
     *out = p;
     return 0;
 }
@@ -258,6 +306,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (!p) return 0;
     (void)hipSetDevice(p->device);
     if (p->d_ctab) (void)hipFree(p->d_ctab);
+    if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
@@ -313,7 +362,8 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(p->device));
     const int ofps = out_floats_per_sample(p);
-    const int nblk = (n + kTile - 1) / kTile;
+    const bool use128 = (p->d_atab != nullptr);
+    const int nblk = use128 ? (n + kFpw128 - 1) / kFpw128 : (n + kTile - 1) / kTile;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     const size_t nx = static_cast<size_t>(batch) * n, no = nx * ofps;
@@ -347,7 +397,8 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         tev = p->ev.data() + p->ev_used;
         HIP_TRY(hipEventRecord(tev[0], st));
     }
-    switch (p->R) {
+    if (use128) rc = launch_core128(p, dx, dout, n, batch, nblk, st);
+    else switch (p->R) {
         case 1: rc = launch_core<1>(p, cp, nblocks, st); break;
         case 2: rc = launch_core<2>(p, cp, nblocks, st); break;
         case 4: rc = launch_core<4>(p, cp, nblocks, st); break;
