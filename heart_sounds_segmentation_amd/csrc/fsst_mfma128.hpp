@@ -26,7 +26,7 @@
 #include "fsst_kernels.hpp"
 
 #ifndef HSS_MW128
-#define HSS_MW128 3
+#define HSS_MW128 4
 #endif
 
 namespace hssfsst {
@@ -56,6 +56,31 @@ constexpr __host__ __device__ int bitrev4(int n) { return ((n & 1) << 3) | ((n &
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Packed complex helpers with VOP3P operand swizzles (op_sel) and sign modifiers (neg_lo/neg_hi):
+// hipcc materialises (y, -x)-style operands with v_xor + v_mov instead of using the modifiers.
+// Inputs of these statements are always results of ordinary VALU instructions (never MFMA
+// destinations), so no manual hazard padding is needed inside the strings.
+__device__ __forceinline__ f2 add_conj(f2 x, f2 p)       // x + conj(p)
+{
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p)); return d;
+}
+__device__ __forceinline__ f2 unpack_vd(f2 x, f2 p)      // (x - conj(p)) / i = (x.y + p.y, p.x - x.x)
+{
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p)); return d;
+}
+__device__ __forceinline__ f2 add_mi(f2 e, f2 o)         // e + (-i) o
+{
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(e), "v"(o)); return d;
+}
+__device__ __forceinline__ f2 sub_mi(f2 e, f2 o)         // e - (-i) o
+{
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(e), "v"(o)); return d;
+}
+__device__ __forceinline__ f2 mul_swap(f2 a, f2 b)       // (a.x b.y, a.y b.x)
+{
+    f2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+
 // Radix-2 DIT butterfly on packed complex values, twiddle W = exp(-2*pi*i*TW/16).
 template <int TW>
 __device__ __forceinline__ void bfly16(f2& e, f2& o)
@@ -64,8 +89,7 @@ __device__ __forceinline__ void bfly16(f2& e, f2& o)
     if constexpr (TW == 0) {
         a = e + o; b = e - o;
     } else if constexpr (TW == 4) {                     // W = -i: W o = (o.im, -o.re)
-        const f2 t = f2{o.y, -o.x};
-        a = e + t; b = e - t;
+        a = add_mi(e, o); b = sub_mi(e, o);
     } else {                                            // W = wr + i wi, wr = cos, wi = -sin
         constexpr float wr = kCos16[TW], wi = -kSin16[TW];
         const f2 t1 = pk_fma(f2{o.x, o.x}, f2{wr, wi}, e);
@@ -91,140 +115,157 @@ __device__ __forceinline__ void fft16(f2 (&z)[16])
     });
 }
 
-// ---- LDS planes of one 16-frame group: [16 frames][LDF] packed complex (re, im) per kept row, plus
-// one dummy column (index K) that swallows the stores of sources whose own row is not kept.
-__host__ __device__ constexpr int plane_ldf(int K) { return (K & 1) ? K + 2 : K + 1; }   // odd => b64 conflict-free
+// ---- LDS planes of one 16-frame group (per wave), packed complex (re, im) per cell:
+//   own  [16 frames][own_ld]  columns for rows 8*s0 .. 8*s1+7, the 8-aligned cover of the kept band:
+//                             source k' stores (-1)^k' V[k'] into its column unconditionally
+//                             (address = per-lane base + compile-time offset); sources whose
+//                             8-row stripe lies outside the cover skip the store (wave-uniform);
+//   disp [16 frames][LDF(K)]  kept rows only, zero-initialised: corrections from displaced sources.
+__host__ __device__ constexpr int odd_up(int v) { return (v & 1) ? v : v + 1; }      // odd => b64 conflict-free
+__host__ __device__ constexpr int plane_ldf(int K) { return odd_up(K); }
+__host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
+__host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
+__host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
+constexpr int kWavesPerBlock = 4;
+__host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
+{
+    return ((fpw + 127 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K) + plane_ldf(K)) + 4;   // + dirty flag
+}
 
-struct SrcEntry { float thr; int off; };      // per (source s, array a/b, lane group): threshold, byte offset of the own slot
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS traffic of one wave is executed in program order: only the compiler must not reorder.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // Exact (rare) path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32.  `row_disp`
 // points at this lane's frame row in the displaced plane; the own plane already holds V in the
-// source's own slot (unconditional store), so V is first taken out again there.
-__device__ __forceinline__ bool displaced_source(f2* row_disp, int klo, int K, int own_off, float kf,
-                                                 bool mirror, float num, float den, f2 V)
+// source's own column (unconditional store), so V is first taken out again there.
+__device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int klo, int K, int kpi,
+                                                 float num, float den, f2 V)
 {
+    const float kf = static_cast<float>(kpi);
     auto add = [&](int idx, float re, float im) {
         float* q = reinterpret_cast<float*>(row_disp + idx);
         __hip_atomic_fetch_add(q, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        *flag = 1;                                      // this wave's displaced plane is no longer zero
     };
-    bool added = false;
-    if (own_off < K * 8) { add(own_off >> 3, -V.x, -V.y); added = true; }
     float shift = num * __builtin_amdgcn_rcpf(den);
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
     const float a = kf + shift;
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
     const int row = static_cast<int>(r) & 127;
-    const int idx = row - klo;
-    if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) { add(idx, V.x, V.y); added = true; }
-    if (mirror) {                                       // negative-frequency twin: row -> 128 - row, value conj
-        const int idm = ((128 - row) & 127) - klo;
-        if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) { add(idm, V.x, -V.y); added = true; }
+    if (row == kpi) return;                             // rounds back into its own row after all
+    const int own = kpi - klo, idx = row - klo;
+    if (static_cast<unsigned>(own) < static_cast<unsigned>(K)) add(own, -V.x, -V.y);
+    if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) add(idx, V.x, V.y);
+    if (kpi != 0) {                                     // negative-frequency twin (k' = 64 never moves)
+        const int idm = ((128 - row) & 127) - klo;      // row -> 128 - row, value conj
+        if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) add(idm, V.x, -V.y);
     }
-    return added;
 }
 
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner
 // P = Z[128 - k'] (Z = FFT of x (w + i dw') / 2 with the sign (-1)^k' folded into the constants):
 //   V = X + conj(P) = (-1)^k' V[k'],   Vd' = (X - conj(P)) / i,   shift = -Im(Vd'/V) = num / den.
-// V is stored unconditionally into the source's own slot (or the dummy column).  `thr`: 1/2 for
-// kept rows (the source stays in its own row iff |shift| < 1/2); for rows outside the kept band
-// the distance to the band minus 1/2 (closer moves cannot reach a kept row, nor can their mirror),
-// so the exact path only runs for sources that may change the output.
-__device__ __forceinline__ bool process_source(f2 X, f2 P, SrcEntry ent, char* row_own, f2* row_disp,
-                                               int klo, int K, float kf, bool mirror)
+// The source stays in its own row iff |shift| < 1/2 iff |num| < den/2 (no division); V == 0
+// contributes nothing wherever it lands.  Only when some lane of the wave has a displaced cell does
+// the wave run the exact rounding path for those lanes.
+template <int S>
+__device__ __forceinline__ void process_source(f2 X, f2 P, f2* own_slot, bool store, f2* row_disp, int* flag,
+                                               int klo, int K, int r)
 {
-    const f2 V = X + f2{P.x, -P.y};
-    const f2 Vd = f2{X.y, -X.x} + f2{P.y, P.x};
+    const f2 V = add_conj(X, P);
+    const f2 Vd = unpack_vd(X, P);
     const f2 sq = V * V;
-    const f2 cr = Vd * f2{V.y, V.x};
+    const f2 cr = mul_swap(Vd, V);
     const float den = sq.x + sq.y;
     const float num = cr.x - cr.y;
-    *reinterpret_cast<f2*>(row_own + ent.off) = V;
-    const bool moved = fabsf(num) >= fmaxf(ent.thr * den, 1.0e-37f);
-    bool added = false;
+    if (store) *own_slot = V;                           // wave-uniform predicate
+    const bool moved = fabsf(num) >= fmaxf(0.5f * den, 1.0e-37f);
     if (__ballot(moved) != 0ull) {
-        if (moved) added = displaced_source(row_disp, klo, K, ent.off, kf, mirror, num, den, V);
+        if (moved) displaced_source(row_disp, flag, klo, K, r + 8 * S, num, den, V);
     }
-    return added;
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid = batch * nblk blocks of ONE wave; wave tile = FPW consecutive frames of one signal, walked
-// in groups of 16 frames.  LDS per wave: xs[FPW + 127] | own[16][LDF] f2 | disp[16][LDF] f2 | tab.
+// grid = batch * ceil(nblk / 4) blocks of 4 waves; each WAVE owns a tile of FPW consecutive frames of
+// one signal and walks it in groups of 16 frames, independently of its sibling waves (no block
+// barrier after the prologue, so the waves drift apart and one wave's MFMA phase overlaps
+// another's VALU phase on the same SIMD).
+// LDS: atab[16 taps][64 lanes][2] (shared, 8 KB) | per wave: xs[FPW+127] | own | disp.
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
-__global__ __launch_bounds__(64, HSS_MW128) void fsst_core128_kernel(Core128Params p)
+__global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_kernel(Core128Params p)
 {
     constexpr int XS = ((FPW + 127 + 3) / 4) * 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.K, klo = p.klo, n = p.n;
     const int LDF = plane_ldf(K);
-    float* xs = smem;
-    f2* own_base = reinterpret_cast<f2*>(smem + XS);
-    f2* disp_base = own_base + 16 * LDF;
-    SrcEntry* tab = reinterpret_cast<SrcEntry*>(disp_base + 16 * LDF);   // [(s*2 + ab)][4 groups], s = 0..8
+    const int OLD = own_ld(klo, K);
+    const int s0 = own_s0(klo), s1 = own_s1(klo, K);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int blk = blockIdx.x % p.nblk;
-    const long long b = blockIdx.x / p.nblk;
+    const int tiles_per_sig_blocks = (p.nblk + kWavesPerBlock - 1) / kWavesPerBlock;
+    const long long b = blockIdx.x / tiles_per_sig_blocks;
+    const int blk = (blockIdx.x % tiles_per_sig_blocks) * kWavesPerBlock + wv;
+
+    f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
+    float* wbase = smem + 2 * 16 * 64 + wv * wave_lds_floats(FPW, klo, K);
+    float* xs = wbase;
+    f2* own_base = reinterpret_cast<f2*>(wbase + XS);
+    f2* disp_base = own_base + 16 * OLD;
+    int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
+
+    // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
+    for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
+        atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
+    const bool live = blk < p.nblk;
     const int t0 = blk * FPW;
     const float* xsig = p.x + b * static_cast<long long>(n);
-
-    float A[32];                                         // MFMA A operand: row (lane&15), k (lane>>4)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) A[i] = p.atab[i * 64 + lane];
-
-    for (int i = lane; i < FPW + 127; i += 64) {         // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
-        const int gi = t0 + i - 64;
-        xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
-    }
-    for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    const bool isg0 = (g == 0);
-    for (int i = lane; i < 18 * 4; i += 64) {            // entry (s, ab, group)
-        const int gg = i & 3, ab = (i >> 2) & 1, s = i >> 3;
-        const int r = ab ? ((gg == 0) ? 4 : 8 - gg) : gg;
-        const int slot = 8 * s + r - klo;
-        const int d = max(slot - (K - 1), -slot);        // > 0: rows outside the kept band
-        SrcEntry ent;
-        ent.thr = (d > 0) ? static_cast<float>(d) - 0.5f : 0.5f;
-        ent.off = (d > 0) ? K * 8 : slot * 8;            // dummy column K
-        if (s == 8 && (ab || gg != 0)) { ent.thr = 3.0e38f; ent.off = K * 8; }   // only k' = 64 (class 0) exists
-        tab[i] = ent;
+    if (live) {
+        for (int i = lane; i < FPW + 127; i += 64) {     // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
+            const int gi = t0 + i - 64;
+            xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+        }
+        for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+        if (lane == 0) *flag = 0;
     }
     __syncthreads();
+    if (!live) return;
 
-    char* row_own = reinterpret_cast<char*>(own_base + j * LDF);
+    const bool isg0 = (g == 0);
+    const int rA = g, rB = isg0 ? 4 : 8 - g;
+    f2* ownA = own_base + j * OLD + rA - 8 * s0;         // column of k' = 8 s + rA at + 8 s
+    f2* ownB = own_base + j * OLD + rB - 8 * s0;
     f2* row_disp = disp_base + j * LDF;
-    const SrcEntry* mytab = tab + g;
-    const float rAf = static_cast<float>(g), rBf = static_cast<float>(isg0 ? 4 : 8 - g);
+    const f2* myA = atab + lane;
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
-    bool dirty = false;
 
     for (int grp = 0; grp < FPW / 16; ++grp) {
         const int tg = t0 + grp * 16;
         if (tg >= n) break;
         const float* xb = xs + grp * 16 + lane;
+        // keep the per-lane class ids opaque inside the loop: otherwise LICM hoists every
+        // "rA + 8 s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
+        int rAi = rA, rBi = rB;
+        asm volatile("" : "+v"(rAi), "+v"(rBi));
 
         // ---- folded window + radix-8 stage on the matrix pipe: 16 taps x 2 k-halves
         f2 za[16], zb[16];
         static_for<16>([&](auto NN) {
             constexpr int nn = decltype(NN)::value;
+            const f2 a2 = myA[nn * 64];
             f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2 * nn], xb[nn], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2 * nn + 1], xb[nn + 64], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, xb[nn], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, xb[nn + 64], acc, 0, 0, 0);
             za[bitrev4(nn)] = f2{acc.x, acc.y};
             zb[bitrev4(nn)] = f2{acc.z, acc.w};
         });
-#ifdef HSS_SGB
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        static_for<14>([&](auto) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        });
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
         fft16(za);
         fft16(zb);
 
@@ -235,24 +276,24 @@ __global__ __launch_bounds__(64, HSS_MW128) void fsst_core128_kernel(Core128Para
             const f2 pa0 = za[(16 - s) & 15], pb = zb[15 - s], pa = za[15 - s];
             const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
             const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
-            dirty |= process_source(za[s], PA, mytab[(s * 2 + 0) * 4], row_own, row_disp, klo, K,
-                                    rAf + static_cast<float>(8 * s), !(isg0 && s == 0));
-            dirty |= process_source(zb[s], PB, mytab[(s * 2 + 1) * 4], row_own, row_disp, klo, K,
-                                    rBf + static_cast<float>(8 * s), true);
+            const bool st = (s >= s0) && (s <= s1);
+            process_source<s>(za[s], PA, ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
+            process_source<s>(zb[s], PB, ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
         });
-        // k' = 64 (class 0, j = 8): its own partner; lanes of other groups idle (thr = huge, dummy slot)
-        dirty |= process_source(za[8], za[8], mytab[(8 * 2 + 0) * 4], row_own, row_disp, klo, K, 64.0f, false);
-        __syncthreads();
+        // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
+        if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
+        wave_sync();
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
-        const bool wdirty = __any(dirty);
+        const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
         const int nvalid = min(16, n - tg);
+        const int koff = klo - 8 * s0;
         if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(n) + tg;
             for (int e = lane; e < K * 16; e += 64) {
                 const int k = e >> 4, jj = e & 15;
                 if (jj < nvalid) {
-                    f2 v = own_base[jj * LDF + k];
+                    f2 v = own_base[jj * OLD + koff + k];
                     if (wdirty) v += disp_base[jj * LDF + k];
                     dst[static_cast<long long>(k) * n + jj] = make_float2(v.x, v.y);
                 }
@@ -264,7 +305,7 @@ __global__ __launch_bounds__(64, HSS_MW128) void fsst_core128_kernel(Core128Para
             int jj = lane / K, k = lane - jj * K;
             const int djj = 64 / K, dk = 64 - djj * K;
             for (int e = lane; e < total; e += 64) {
-                f2 v = own_base[jj * LDF + k];
+                f2 v = own_base[jj * OLD + koff + k];
                 if (wdirty) v += disp_base[jj * LDF + k];
                 if (p.mode == kModeAbs) {
                     dst[jj * C + k] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
@@ -278,11 +319,11 @@ __global__ __launch_bounds__(64, HSS_MW128) void fsst_core128_kernel(Core128Para
                 if (k >= K) { k -= K; ++jj; }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (wdirty) {
             for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-            dirty = false;
-            __syncthreads();
+            if (lane == 0) *flag = 0;
+            wave_sync();
         }
     }
     if (p.mode != kModeStack) return;

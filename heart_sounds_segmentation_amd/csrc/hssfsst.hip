@@ -148,8 +148,9 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
 
 int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, int n, int64_t batch, int nblk, hipStream_t st)
 {
-    constexpr int XS = ((kFpw128 + 127 + 3) / 4) * 4;
-    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * 2 * 16 * hssfsst::plane_ldf(pl->K)) + 72 * 2) * sizeof(float);
+    const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
+                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
+    if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     hssfsst::Core128Params cp;
     cp.x = dx; cp.out = dout; cp.partials = pl->d_partials; cp.atab = pl->d_atab;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk;
@@ -157,7 +158,8 @@ int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, int n, 
     if (lds > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(batch * nblk)), dim3(64), lds, st, cp);
+    const int64_t bps = (nblk + hssfsst::kWavesPerBlock - 1) / hssfsst::kWavesPerBlock;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(batch * bps)), dim3(64 * hssfsst::kWavesPerBlock), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
 }
