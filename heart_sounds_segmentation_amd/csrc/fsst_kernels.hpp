@@ -360,48 +360,63 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
 // ------------------------------------------------------------------------------------------------
 // STACK epilogue, second half of FSST._stack_real_imag (synchrosqueeze.py:78-85): per signal mean
 // and UNBIASED std of the real block and of the imag block over all K*n elements, then
-// (v - mean) / std in float32, in place.  Streams the signal's n*2K floats once (L2/MALL-warm).
+// (v - mean) / std in float32, in place (evaluated as (v - mean) * (1/std): <= 1.5 ulp from the
+// reference's division).  Pure streaming, in place: linear float4 grid-stride sweep per signal.
 // grid = (chunks, batch), block = 256.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const double* partials,
-                                                             int nblk, int n, int K)
+// Per-signal statistics from the per-tile fp64 partials: one wave per signal, fixed reduction order.
+// stats[b] = {mean_re, 1/std_re, mean_im, 1/std_im} (float32, as the reference's float32 tensors).
+__global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, float4* stats, int nblk,
+                                                        int n, int K)
 {
-    __shared__ float stat[4];   // mean_re, std_re, mean_im, std_im
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double* part = partials + b * nblk * 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int i = lane; i < nblk; i += 64) { a0 += part[i * 4]; a1 += part[i * 4 + 1]; a2 += part[i * 4 + 2]; a3 += part[i * 4 + 3]; }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {
+        const double cnt = static_cast<double>(K) * static_cast<double>(n);
+        const double mr = a0 / cnt, mi = a2 / cnt;
+        const double vr = (a1 - a0 * mr) / (cnt - 1.0), vi = (a3 - a2 * mi) / (cnt - 1.0);
+        stats[b] = make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
+                               static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
+    }
+}
+
+__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, int n, int K)
+{
     const long long b = blockIdx.y;
     const int tid = threadIdx.x;
-    if (tid < 2) {
-        const double* part = partials + b * nblk * 4 + tid * 2;
-        double s = 0.0, q = 0.0;
-        for (int i = 0; i < nblk; ++i) { s += part[i * 4]; q += part[i * 4 + 1]; }
-        const double cnt = static_cast<double>(K) * static_cast<double>(n);
-        const double mean = s / cnt;
-        const double var = (q - s * mean) / (cnt - 1.0);
-        stat[tid * 2] = static_cast<float>(mean);
-        stat[tid * 2 + 1] = static_cast<float>(sqrt(var));
-    }
-    __syncthreads();
-    const float m_re = stat[0], s_re = stat[1], m_im = stat[2], s_im = stat[3];
+    const float4 st = stats[b];
+    const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
     const int C = 2 * K;
-    const long long total = static_cast<long long>(n) * C;
-    float* base = out + b * total;
-    const long long stride = static_cast<long long>(gridDim.x) * 256;
+    float* base = out + b * static_cast<long long>(n) * C;
+    const int total = n * C;                             // per-signal element count (< 2^31, checked on the host)
     if ((C & 3) == 0) {
+        // linear float4 grid-stride sweep of the signal's block; the column of a chunk is tracked
+        // incrementally (no integer division in the loop)
         float4* b4 = reinterpret_cast<float4*>(base);
-        const long long tot4 = total >> 2;
-        for (long long i = static_cast<long long>(blockIdx.x) * 256 + tid; i < tot4; i += stride) {
+        const int tot4 = total >> 2;
+        const int stride = gridDim.x * 256;
+        int i = blockIdx.x * 256 + tid;
+        int c = static_cast<int>((static_cast<unsigned>(i) * 4u) % static_cast<unsigned>(C));
+        const int dc = static_cast<int>((static_cast<unsigned>(stride) * 4u) % static_cast<unsigned>(C));
+        for (; i < tot4; i += stride) {
             float4 v = b4[i];
-            const int c = static_cast<int>((i * 4) % C);
-            v.x = (c + 0 < K) ? (v.x - m_re) / s_re : (v.x - m_im) / s_im;
-            v.y = (c + 1 < K) ? (v.y - m_re) / s_re : (v.y - m_im) / s_im;
-            v.z = (c + 2 < K) ? (v.z - m_re) / s_re : (v.z - m_im) / s_im;
-            v.w = (c + 3 < K) ? (v.w - m_re) / s_re : (v.w - m_im) / s_im;
+            v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+            v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+            v.z = (c + 2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+            v.w = (c + 3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
             b4[i] = v;
+            c += dc;
+            if (c >= C) c -= C;
         }
     } else {
-        for (long long i = static_cast<long long>(blockIdx.x) * 256 + tid; i < total; i += stride) {
-            const int c = static_cast<int>(i % C);
+        for (int i = blockIdx.x * 256 + tid; i < total; i += gridDim.x * 256) {
+            const int c = i % C;
             const float v = base[i];
-            base[i] = (c < K) ? (v - m_re) / s_re : (v - m_im) / s_im;
+            base[i] = (c < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
         }
     }
 }

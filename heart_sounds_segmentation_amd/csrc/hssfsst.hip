@@ -119,11 +119,13 @@ struct hssfsst_plan {
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
     float* d_atab = nullptr;      // nwin == 128: MFMA A-operand constants [32][64]
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
+    float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
     int timing = 0;
-    std::vector<hipEvent_t> ev;   // 3 per timed exec
+    std::vector<hipEvent_t> ev;   // per timed exec: (before, after) per core launch + one closing event
     size_t ev_used = 0;           // events used since timing was enabled
+    std::vector<int> ev_chunks;   // core launches of each timed exec
 };
 
 namespace {
@@ -146,13 +148,13 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
     return 0;
 }
 
-int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, int n, int64_t batch, int nblk, hipStream_t st)
+int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int64_t batch, int nblk, hipStream_t st)
 {
     const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     hssfsst::Core128Params cp;
-    cp.x = dx; cp.out = dout; cp.partials = pl->d_partials; cp.atab = pl->d_atab;
+    cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk;
     auto kern = hssfsst::fsst_core128_kernel<kFpw128>;
     if (lds > 32 * 1024)
@@ -310,6 +312,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_ctab) (void)hipFree(p->d_ctab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
+    if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
@@ -336,6 +339,7 @@ int hssfsst_plan_set_timing(hssfsst_plan* p, int enable)
     if (!p) return fail(HSSFSST_EINVAL, "plan_set_timing: plan is NULL");
     p->timing = enable ? 1 : 0;
     p->ev_used = 0;
+    p->ev_chunks.clear();
     return 0;
 }
 
@@ -343,15 +347,22 @@ int hssfsst_plan_timing(hssfsst_plan* p, float ms_sum[2], int* nexec)
 {
     if (!p || !ms_sum || !nexec) return fail(HSSFSST_EINVAL, "plan_timing: bad argument");
     ms_sum[0] = ms_sum[1] = 0.0f;
-    *nexec = static_cast<int>(p->ev_used / 3);
+    *nexec = static_cast<int>(p->ev_chunks.size());
     if (p->ev_used == 0) return 0;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev[p->ev_used - 1]));
-    for (size_t i = 0; i + 2 < p->ev_used; i += 3) {
-        float a = 0.0f, b = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&a, p->ev[i], p->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&b, p->ev[i + 1], p->ev[i + 2]));
-        ms_sum[0] += a; ms_sum[1] += b;
+    size_t i = 0;
+    for (int nc : p->ev_chunks) {
+        float core = 0.0f, total = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            float a = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&a, p->ev[i + 2 * c], p->ev[i + 2 * c + 1]));
+            core += a;
+        }
+        HIP_TRY(hipEventElapsedTime(&total, p->ev[i], p->ev[i + 2 * nc]));
+        ms_sum[0] += core;
+        ms_sum[1] += total - core;
+        i += 2 * static_cast<size_t>(nc) + 1;
     }
     return 0;
 }
@@ -368,6 +379,7 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
     const int nblk = use128 ? (n + kFpw128 - 1) / kFpw128 : (n + kTile - 1) / kTile;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
+    if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
     const size_t nx = static_cast<size_t>(batch) * n, no = nx * ofps;
 
     const float* dx = x;
@@ -383,46 +395,83 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         dout = p->d_ostage;
     }
     if (p->mode == HSSFSST_MODE_STACK)
+    {
         if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * 4, sizeof(double))) != 0) return rc;
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
+    }
 
     hssfsst::CoreParams cp;
     cp.x = dx; cp.out = dout; cp.partials = p->d_partials; cp.ctab = p->d_ctab;
     cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk;
 
-    hipEvent_t* tev = nullptr;
-    if (p->timing) {
-        while (p->ev.size() < p->ev_used + 3) {
+    auto next_event = [&](hipEvent_t* out_ev) -> int {
+        if (p->ev.size() <= p->ev_used) {
             hipEvent_t e2 = nullptr;
             HIP_TRY(hipEventCreate(&e2));
             p->ev.push_back(e2);
         }
-        tev = p->ev.data() + p->ev_used;
-        HIP_TRY(hipEventRecord(tev[0], st));
-    }
-    if (use128) rc = launch_core128(p, dx, dout, n, batch, nblk, st);
-    else switch (p->R) {
-        case 1: rc = launch_core<1>(p, cp, nblocks, st); break;
-        case 2: rc = launch_core<2>(p, cp, nblocks, st); break;
-        case 4: rc = launch_core<4>(p, cp, nblocks, st); break;
-        case 8: rc = launch_core<8>(p, cp, nblocks, st); break;
-        case 16: rc = launch_core<16>(p, cp, nblocks, st); break;
-        default: rc = fail(HSSFSST_EUNSUPPORTED, "exec: unsupported radix %d", p->R);
-    }
-    if (rc != 0) return rc;
-    if (tev) HIP_TRY(hipEventRecord(tev[1], st));
+        *out_ev = p->ev[p->ev_used++];
+        return 0;
+    };
+    int timed_chunks = 0;
+    // STACK: the z-score kernel re-reads what the core kernel just wrote.  Optional chunking of the
+    // batch (HSSFSST_CHUNK_MB) was measured on MI355X: keeping the re-read inside the 256 MiB Infinity
+    // Cache does NOT beat one full-batch sweep (the sweep already runs at the in-place streaming rate
+    // of ~6 TB/s, and small launches lose more on tails), so the default is a single chunk.
+    int64_t chunk = batch;
+    const int64_t per = static_cast<int64_t>(n) * ofps;
     if (p->mode == HSSFSST_MODE_STACK) {
-        const long long per = static_cast<long long>(n) * ofps;
-        long long chunks = (per / 4 + 255) / 256;
-        if (chunks > 16) chunks = 16;
-        if (chunks < 1) chunks = 1;
-        for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
-            const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
-            hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(nb)),
-                               dim3(256), 0, st, dout + b0 * per, p->d_partials + b0 * nblk * 4, nblk, n, p->K);
+        const char* ce = std::getenv("HSSFSST_CHUNK_MB");
+        const double mb = ce ? std::atof(ce) : 0.0;
+        if (mb > 0) {
+            chunk = static_cast<int64_t>(mb * 1048576.0 / (static_cast<double>(per) * sizeof(float)));
+            if (chunk < 1) chunk = 1;
+            if (chunk > batch) chunk = batch;
         }
-        HIP_TRY(hipGetLastError());
     }
-    if (tev) { HIP_TRY(hipEventRecord(tev[2], st)); p->ev_used += 3; }
+    for (int64_t c0 = 0; c0 < batch; c0 += chunk) {
+        const int64_t cb = (batch - c0 < chunk) ? batch - c0 : chunk;
+        const float* cx = dx + c0 * n;
+        float* cout = dout + c0 * per;
+        hssfsst::CoreParams cp;
+        cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * 4 : nullptr; cp.ctab = p->d_ctab;
+        cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk;
+        const long long cblocks = static_cast<long long>(cb) * nblk;
+        hipEvent_t evt = nullptr;
+        if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
+        if (use128) {
+            rc = launch_core128(p, cx, cout, cp.partials, n, cb, nblk, st);
+        } else switch (p->R) {
+            case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
+            case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
+            case 4: rc = launch_core<4>(p, cp, cblocks, st); break;
+            case 8: rc = launch_core<8>(p, cp, cblocks, st); break;
+            case 16: rc = launch_core<16>(p, cp, cblocks, st); break;
+            default: rc = fail(HSSFSST_EUNSUPPORTED, "exec: unsupported radix %d", p->R);
+        }
+        if (rc != 0) return rc;
+        if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
+        if (p->mode == HSSFSST_MODE_STACK) {
+            long long chunks = (per / 4 + 511) / 512;      // two float4 per thread
+            if (chunks > 1024) chunks = 1024;
+            if (chunks < 1) chunks = 1;
+            float4* cstats = reinterpret_cast<float4*>(p->d_stats) + c0;
+            hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, st,
+                               cp.partials, cstats, nblk, n, p->K);
+            for (int64_t b0 = 0; b0 < cb; b0 += 65535) {
+                const int64_t nb = (cb - b0 < 65535) ? cb - b0 : 65535;
+                hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(nb)),
+                                   dim3(256), 0, st, cout + b0 * per, cstats + b0, n, p->K);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (p->timing) {
+        hipEvent_t evt = nullptr;
+        if ((rc = next_event(&evt)) != 0) return rc;
+        HIP_TRY(hipEventRecord(evt, st));
+        p->ev_chunks.push_back(timed_chunks);
+    }
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

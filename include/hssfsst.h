@@ -71,10 +71,11 @@ int hssfsst_exec(hssfsst_plan* plan, const float* x, int64_t batch, int n, int x
                  float* out, int out_on_device, void* stream);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
- * hssfsst_exec records an event triple around its kernels WITHOUT synchronising; enabling resets
- * the record.  hssfsst_plan_timing() synchronises once and returns, over all execs since enabling:
- * ms_sum[0] = total synchrosqueeze-core kernel time, ms_sum[1] = total normalisation kernel time
- * (0 unless STACK), both in milliseconds, and *nexec = number of execs recorded. */
+ * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
+ * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the
+ * record.  hssfsst_plan_timing() synchronises once and returns, over all execs since enabling:
+ * ms_sum[0] = total synchrosqueeze-core kernel time, ms_sum[1] = rest of the exec (z-score kernels,
+ * 0 unless STACK), both in milliseconds, and *nexec = number of execs recorded. */
 int hssfsst_plan_set_timing(hssfsst_plan* plan, int enable);
 int hssfsst_plan_timing(hssfsst_plan* plan, float ms_sum[2], int* nexec);
 
