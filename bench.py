@@ -138,7 +138,7 @@ def main():
             "config": {"workload": f"C2: {B} x {n} fp32 synthetic PCG windows per GPU, fs=1000, "
                                    "Kaiser(128,0.5), band [25,200] Hz, stack=True -> (2000,44) fp32",
                        "windows_per_gpu": B, "parallelism": f"window-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "fsst_core_kernel<4,64>",
+            "roofline": {"bound": "hbm", "kernel": "fsst_core128_kernel<64>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_WINDOW * B,
