@@ -299,24 +299,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                 }
             }
         } else {
+            // lane (g, j): frame j, kept rows k = g, g + 4, g + 8 ...: LDS and HBM addresses are a
+            // per-lane base plus a multiple of the loop index (no index arithmetic in the loop);
+            // the 4 lanes of a frame write 16 contiguous bytes per step.
             const int C = (p.mode == kModeAbs) ? K : 2 * K;
-            float* dst = p.out + (b * static_cast<long long>(n) + tg) * C;
-            const int total = nvalid * K;
-            int jj = lane / K, k = lane - jj * K;
-            const int djj = 64 / K, dk = 64 - djj * K;
-            for (int e = lane; e < total; e += 64) {
-                f2 v = own_base[jj * OLD + koff + k];
-                if (wdirty) v += disp_base[jj * LDF + k];
+            if (j < nvalid) {
+                float* dst = p.out + (b * static_cast<long long>(n) + tg + j) * C + g;
+                const f2* src = own_base + j * OLD + koff + g;
+                const f2* dsp = disp_base + j * LDF + g;
+                const int steps = (K - g + 3) >> 2;          // rows g + 4 i < K
                 if (p.mode == kModeAbs) {
-                    dst[jj * C + k] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+                    for (int i = 0; i < steps; ++i) {
+                        f2 v = src[4 * i];
+                        if (wdirty) v += dsp[4 * i];
+                        dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+                    }
                 } else {
-                    dst[jj * C + k] = v.x;
-                    dst[jj * C + K + k] = v.y;
-                    st_s += v;
-                    st_q = pk_fma(v, v, st_q);
+                    float* dsti = dst + K;
+                    for (int i = 0; i < steps; ++i) {
+                        f2 v = src[4 * i];
+                        if (wdirty) v += dsp[4 * i];
+                        dst[4 * i] = v.x;
+                        dsti[4 * i] = v.y;
+                        st_s += v;
+                        st_q = pk_fma(v, v, st_q);
+                    }
                 }
-                k += dk; jj += djj;
-                if (k >= K) { k -= K; ++jj; }
             }
         }
         wave_sync();
