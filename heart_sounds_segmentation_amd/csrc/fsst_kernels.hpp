@@ -384,39 +384,42 @@ __global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, 
     }
 }
 
-__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, int n, int K)
+// grid = any number of blocks of 256 (the host sizes it to a fraction of the chip so the sweep can
+// share the GPU with a concurrently running core kernel); block b handles signals b, b + grid, ...
+__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, int n, int K,
+                                                             int nsignals)
 {
-    const long long b = blockIdx.y;
     const int tid = threadIdx.x;
-    const float4 st = stats[b];
-    const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
     const int C = 2 * K;
-    float* base = out + b * static_cast<long long>(n) * C;
     const int total = n * C;                             // per-signal element count (< 2^31, checked on the host)
-    if ((C & 3) == 0) {
-        // linear float4 grid-stride sweep of the signal's block; the column of a chunk is tracked
-        // incrementally (no integer division in the loop)
-        float4* b4 = reinterpret_cast<float4*>(base);
-        const int tot4 = total >> 2;
-        const int stride = gridDim.x * 256;
-        int i = blockIdx.x * 256 + tid;
-        int c = static_cast<int>((static_cast<unsigned>(i) * 4u) % static_cast<unsigned>(C));
-        const int dc = static_cast<int>((static_cast<unsigned>(stride) * 4u) % static_cast<unsigned>(C));
-        for (; i < tot4; i += stride) {
-            float4 v = b4[i];
-            v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
-            v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
-            v.z = (c + 2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
-            v.w = (c + 3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
-            b4[i] = v;
-            c += dc;
-            if (c >= C) c -= C;
-        }
-    } else {
-        for (int i = blockIdx.x * 256 + tid; i < total; i += gridDim.x * 256) {
-            const int c = i % C;
-            const float v = base[i];
-            base[i] = (c < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
+    for (int sig = blockIdx.x; sig < nsignals; sig += gridDim.x) {
+        const float4 st = stats[sig];
+        const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
+        float* base = out + static_cast<long long>(sig) * total;
+        if ((C & 3) == 0) {
+            // linear float4 sweep of the signal's block; the column of a chunk is tracked
+            // incrementally (no integer division in the loop)
+            float4* b4 = reinterpret_cast<float4*>(base);
+            const int tot4 = total >> 2;
+            int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
+            const int dc = static_cast<int>(1024u % static_cast<unsigned>(C));
+#pragma unroll 4
+            for (int i = tid; i < tot4; i += 256) {
+                float4 v = b4[i];
+                v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+                v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+                v.z = (c + 2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+                v.w = (c + 3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
+                b4[i] = v;
+                c += dc;
+                if (c >= C) c -= C;
+            }
+        } else {
+            for (int i = tid; i < total; i += 256) {
+                const int c = i % C;
+                const float v = base[i];
+                base[i] = (c < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
+            }
         }
     }
 }

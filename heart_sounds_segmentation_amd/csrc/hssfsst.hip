@@ -126,6 +126,8 @@ struct hssfsst_plan {
     std::vector<hipEvent_t> ev;   // per timed exec: (before, after) per core launch + one closing event
     size_t ev_used = 0;           // events used since timing was enabled
     std::vector<int> ev_chunks;   // core launches of each timed exec
+    hipStream_t aux = nullptr;    // side stream: z-score of chunk i overlaps the core of chunk i+1
+    std::vector<hipEvent_t> sync_ev;
 };
 
 namespace {
@@ -316,6 +318,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : p->sync_ev) if (ev) (void)hipEventDestroy(ev);
+    if (p->aux) (void)hipStreamDestroy(p->aux);
     delete p;
     return 0;
 }
@@ -414,22 +418,31 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         return 0;
     };
     int timed_chunks = 0;
-    // STACK: the z-score kernel re-reads what the core kernel just wrote.  Optional chunking of the
-    // batch (HSSFSST_CHUNK_MB) was measured on MI355X: keeping the re-read inside the 256 MiB Infinity
-    // Cache does NOT beat one full-batch sweep (the sweep already runs at the in-place streaming rate
-    // of ~6 TB/s, and small launches lose more on tails), so the default is a single chunk.
-    int64_t chunk = batch;
+    // STACK: core (FP32-issue-bound) then the z-score sweep (HBM-bound, in place).  An optional
+    // pipeline (HSSFSST_CHUNKS=k) cuts the batch into k chunks and runs the sweep of chunk i on a side
+    // stream while the core of chunk i+1 runs on the caller's stream.  Measured on MI355X
+    // (tools/chunk_sweep.sh): the overlap LOSES -- the saturating sweep back-pressures the core's own
+    // stores (core 0.25 -> 0.32-0.41 ms per 1024 windows) -- and keeping a chunk inside the 256 MiB
+    // Infinity Cache does not speed the sweep up either, so the default is k = 1.
     const int64_t per = static_cast<int64_t>(n) * ofps;
+    int64_t nchunks = 1;
     if (p->mode == HSSFSST_MODE_STACK) {
-        const char* ce = std::getenv("HSSFSST_CHUNK_MB");
-        const double mb = ce ? std::atof(ce) : 0.0;
-        if (mb > 0) {
-            chunk = static_cast<int64_t>(mb * 1048576.0 / (static_cast<double>(per) * sizeof(float)));
-            if (chunk < 1) chunk = 1;
-            if (chunk > batch) chunk = batch;
+        const char* ce = std::getenv("HSSFSST_CHUNKS");
+        if (ce && std::atoi(ce) > 0) nchunks = std::atoi(ce);
+        if (nchunks > batch) nchunks = batch;
+    }
+    const int64_t chunk = (batch + nchunks - 1) / nchunks;
+    const bool piped = nchunks > 1;
+    if (piped) {
+        if (!p->aux) HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+        while (static_cast<int64_t>(p->sync_ev.size()) < nchunks + 1) {
+            hipEvent_t e2 = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            p->sync_ev.push_back(e2);
         }
     }
-    for (int64_t c0 = 0; c0 < batch; c0 += chunk) {
+    int ci = 0;
+    for (int64_t c0 = 0; c0 < batch; c0 += chunk, ++ci) {
         const int64_t cb = (batch - c0 < chunk) ? batch - c0 : chunk;
         const float* cx = dx + c0 * n;
         float* cout = dout + c0 * per;
@@ -452,19 +465,26 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         if (rc != 0) return rc;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
         if (p->mode == HSSFSST_MODE_STACK) {
-            long long chunks = (per / 4 + 511) / 512;      // two float4 per thread
-            if (chunks > 1024) chunks = 1024;
-            if (chunks < 1) chunks = 1;
-            float4* cstats = reinterpret_cast<float4*>(p->d_stats) + c0;
-            hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, st,
-                               cp.partials, cstats, nblk, n, p->K);
-            for (int64_t b0 = 0; b0 < cb; b0 += 65535) {
-                const int64_t nb = (cb - b0 < 65535) ? cb - b0 : 65535;
-                hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(nb)),
-                                   dim3(256), 0, st, cout + b0 * per, cstats + b0, n, p->K);
+            hipStream_t zs = st;
+            if (piped) {
+                HIP_TRY(hipEventRecord(p->sync_ev[ci], st));
+                HIP_TRY(hipStreamWaitEvent(p->aux, p->sync_ev[ci], 0));
+                zs = p->aux;
             }
+            float4* cstats = reinterpret_cast<float4*>(p->d_stats) + c0;
+            hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, zs,
+                               cp.partials, cstats, nblk, n, p->K);
+            static const int zgrid_env = std::getenv("HSSFSST_ZGRID") ? std::atoi(std::getenv("HSSFSST_ZGRID")) : 0;
+            int64_t zgrid = zgrid_env > 0 ? zgrid_env : (piped ? 512 : 4096);
+            if (zgrid > cb) zgrid = cb;
+            hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, zs,
+                               cout, cstats, n, p->K, static_cast<int>(cb));
             HIP_TRY(hipGetLastError());
         }
+    }
+    if (piped && p->mode == HSSFSST_MODE_STACK) {          // the caller's stream owns the result again
+        HIP_TRY(hipEventRecord(p->sync_ev[nchunks], p->aux));
+        HIP_TRY(hipStreamWaitEvent(st, p->sync_ev[nchunks], 0));
     }
     if (p->timing) {
         hipEvent_t evt = nullptr;

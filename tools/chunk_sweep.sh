@@ -1,4 +1,4 @@
-for mb in 0 180 96 45; do echo "== HSSFSST_CHUNK_MB=$mb"; HSSFSST_CHUNK_MB=$mb python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | python -c "
+for cfg in "1 0" "1 256" "1 512" "1 1024" "4 256" "4 512" "4 128" "2 512" "8 256"; do set -- $cfg; echo "== CHUNKS=$1 ZGRID=$2"; HSSFSST_CHUNKS=$1 HSSFSST_ZGRID=$2 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
