@@ -245,6 +245,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     f2* row_disp = disp_base + j * LDF;
     const f2* myA = atab + lane;
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
+    // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
+    // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
+    const bool fast_out = (p.mode == kModeStack || p.mode == kModeStackUnnorm) && ((K & 1) == 0) && (K <= 24);
+    int P0[3], P1[3];
+    {
+        const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
+        const int koff0 = klo - 8 * s0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = lane + 64 * i;
+            const int jj = min(f / Q, 15), c = 4 * (f - (f / Q) * Q);
+            const int rowb = jj * OLD + koff0;
+            P0[i] = (c < K) ? (rowb + c) * 8 : (rowb + c - K) * 8 + 4;
+            P1[i] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
+        }
+    }
 
     for (int grp = 0; grp < FPW / 16; ++grp) {
         const int tg = t0 + grp * 16;
@@ -266,9 +282,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             za[bitrev4(nn)] = f2{acc.x, acc.y};
             zb[bitrev4(nn)] = f2{acc.z, acc.w};
         });
+#if !defined(HSS_ABLATE) || HSS_ABLATE < 3
         fft16(za);
         fft16(zb);
-
+#endif
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 2
+        {   // keep the results alive without the source stage
+            f2 acc = {0.0f, 0.0f};
+            static_for<16>([&](auto I) { acc += za[decltype(I)::value] + zb[decltype(I)::value]; });
+            if (s1 >= 0 && isg0) own_base[j * OLD] = acc;
+        }
+#else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
         static_for<8>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         });
         // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
         if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
+#endif
         wave_sync();
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
@@ -299,26 +324,59 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                 }
             }
         } else {
-            // lane (g, j): frame j, kept rows k = g, g + 4, g + 8 ...: LDS and HBM addresses are a
-            // per-lane base plus a multiple of the loop index (no index arithmetic in the loop);
-            // the 4 lanes of a frame write 16 contiguous bytes per step.
+            // lane (g, j): frame j, kept rows k = g, g + 4, g + 8 ... as packed (re, im) pairs
             const int C = (p.mode == kModeAbs) ? K : 2 * K;
-            if (j < nvalid) {
-                float* dst = p.out + (b * static_cast<long long>(n) + tg + j) * C + g;
-                const f2* src = own_base + j * OLD + koff + g;
-                const f2* dsp = disp_base + j * LDF + g;
-                const int steps = (K - g + 3) >> 2;          // rows g + 4 i < K
-                if (p.mode == kModeAbs) {
-                    for (int i = 0; i < steps; ++i) {
-                        f2 v = src[4 * i];
-                        if (wdirty) v += dsp[4 * i];
-                        dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+            const int steps = (K - g + 3) >> 2;              // rows g + 4 i < K
+            f2* src = own_base + j * OLD + koff + g;
+            const f2* dsp = disp_base + j * LDF + g;
+            if (fast_out) {
+                // (1) fold the displaced plane into the own plane (rare) and take the statistics
+                if (wdirty || p.mode == kModeStack) {
+                    for (int i0 = 0; i0 < steps; i0 += 6) {
+                        f2 v[6];
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) v[u] = (i0 + u < steps) ? src[4 * (i0 + u)] : f2{0.0f, 0.0f};
+                        if (wdirty) {
+#pragma unroll
+                            for (int u = 0; u < 6; ++u)
+                                if (i0 + u < steps) { v[u] += dsp[4 * (i0 + u)]; src[4 * (i0 + u)] = v[u]; }
+                        }
+                        if (j < nvalid) {
+#pragma unroll
+                            for (int u = 0; u < 6; ++u) { st_s += v[u]; st_q = pk_fma(v[u], v[u], st_q); }
+                        }
                     }
-                } else {
-                    float* dsti = dst + K;
-                    for (int i = 0; i < steps; ++i) {
-                        f2 v = src[4 * i];
-                        if (wdirty) v += dsp[4 * i];
+                    wave_sync();
+                }
+                // (2) the group's nvalid x 2K floats are contiguous in HBM: 16-byte stores, lane-linear.
+                //     Each float4 = two adjacent (re,re) or (im,im) pairs of one frame row.
+                const char* ob = reinterpret_cast<const char*>(own_base);
+                float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(n) + tg) * C) + lane;
+                const int lim = nvalid * (K >> 1);
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 1
+                if (tg == 123456789)
+#endif
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (lane + 64 * i < lim) {
+                        float4 o;
+                        o.x = *reinterpret_cast<const float*>(ob + P0[i]);
+                        o.y = *reinterpret_cast<const float*>(ob + P0[i] + 8);
+                        o.z = *reinterpret_cast<const float*>(ob + P1[i]);
+                        o.w = *reinterpret_cast<const float*>(ob + P1[i] + 8);
+                        dst4[64 * i] = o;
+                    }
+                }
+            } else if (j < nvalid) {
+                float* dst = p.out + (b * static_cast<long long>(n) + tg + j) * C + g;
+                const bool isabs = (p.mode == kModeAbs);
+                float* dsti = dst + K;
+                for (int i = 0; i < steps; ++i) {
+                    f2 v = src[4 * i];
+                    if (wdirty) v += dsp[4 * i];
+                    if (isabs) {
+                        dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+                    } else {
                         dst[4 * i] = v.x;
                         dsti[4 * i] = v.y;
                         st_s += v;
