@@ -264,3 +264,48 @@ def test_unnormalized_and_device_moments(oracle_mod):
             assert st[b, off] == k
             assert abs(st[b, off + 1] - m) <= 1e-9 * max(1.0, abs(m))
             assert abs(st[b, off + 2] - var) <= 1e-9 * var
+
+
+def _run_child(env_extra, code):
+    import subprocess, sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    return res.stdout
+
+
+_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from heart_sounds_segmentation_amd import FSST, synth
+w = synth.kaiser_window(128, 0.5)
+outs = []
+for B, n in ((96, 2000), (5, 777), (3, 4100)):
+    X = torch.from_numpy(synth.pcg_windows(B, n, seed=B + n)).cuda()
+    outs.append(FSST(1000, w, truncate_freq=(25, 200), stack=True).batch(X).cpu().numpy())
+    outs.append(FSST(1000, w, truncate_freq=(25, 200), abs=True).batch(X).cpu().numpy())
+    outs.append(np.ascontiguousarray(FSST(1000, w).batch(X[:2]).cpu().numpy()).view(np.float32))
+np.savez(sys.argv[1], *outs)
+'''
+
+
+def test_kernel_variants_agree(tmp_path):
+    """The library's alternative execution paths must reproduce the default one:
+    fused in-kernel z-score (ticket / release-acquire) and the 2-stream chunk pipeline bit-exactly;
+    the generic VALU kernel (forced for nwin = 128) to the parity tolerance."""
+    paths = {}
+    for tag, env in (("default", {}), ("fused", {"HSSFSST_FUSED_ZSCORE": "1"}),
+                     ("piped", {"HSSFSST_CHUNKS": "3"}), ("generic", {"HSSFSST_FORCE_GENERIC": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        _run_child(env, _CHILD.replace("sys.argv[1]", repr(out)))
+        paths[tag] = np.load(out)
+    ref = paths["default"]
+    for k in ref.files:
+        assert np.array_equal(ref[k], paths["fused"][k], equal_nan=True), ("fused", k)
+        assert np.array_equal(ref[k], paths["piped"][k], equal_nan=True), ("piped", k)
+        g = paths["generic"][k]
+        scale = np.abs(ref[k]).max()
+        colerr = np.abs(g - ref[k]).reshape(ref[k].shape[0], -1)
+        # different kernels => different fp32 rounding; allow isolated tie flips (<= 0.1 % of cells)
+        assert (colerr > parity.TOL * scale).mean() < 1e-3, ("generic", k, colerr.max(), scale)
