@@ -33,7 +33,6 @@ namespace hssfsst {
 
 using f2 = float __attribute__((ext_vector_type(2)));
 using f4 = float __attribute__((ext_vector_type(4)));
-using u4 = unsigned __attribute__((ext_vector_type(4)));
 
 struct Core128Params {
     const float* x;       // [batch][n]
@@ -45,7 +44,6 @@ struct Core128Params {
     int K;
     int mode;
     int nblk;             // wave tiles per signal
-    int* counters;        // [batch] arrival counters (zeroed per launch) or NULL: fused z-score off
 };
 
 // cos / sin of 2*pi*j/16, j = 0..7
@@ -238,6 +236,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         if (lane == 0) *flag = 0;
     }
     __syncthreads();
+    if (!live) return;
 
     const bool isg0 = (g == 0);
     const int rA = g, rB = isg0 ? 4 : 8 - g;
@@ -249,12 +248,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
     const bool fast_out = (p.mode == kModeStack || p.mode == kModeStackUnnorm) && ((K & 1) == 0) && (K <= 24);
-    const bool fused = (p.counters != nullptr);          // host enables it only together with fast_out
-    // buffer descriptor of this signal's output block (wave-uniform inputs => no waterfall loop)
-    const long long sig_bytes = static_cast<long long>(n) * 2 * K * 4;
-    float* sig_ptr = p.out + b * static_cast<long long>(n) * 2 * K;
-    const __amdgpu_buffer_rsrc_t sig_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        sig_ptr, 0, static_cast<int>(sig_bytes < 0x7fffffffLL ? sig_bytes : 0x7fffffffLL), 0x00020000);
     int P0[3], P1[3];
     {
         const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
@@ -269,7 +262,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         }
     }
 
-    for (int grp = 0; live && grp < FPW / 16; ++grp) {
+    for (int grp = 0; grp < FPW / 16; ++grp) {
         const int tg = t0 + grp * 16;
         if (tg >= n) break;
         const float* xb = xs + grp * 16 + lane;
@@ -359,7 +352,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                 //     Each float4 = two adjacent (re,re) or (im,im) pairs of one frame row.
                 const char* ob = reinterpret_cast<const char*>(own_base);
                 float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(n) + tg) * C) + lane;
-                const int goff = (tg * C + lane * 4) * 4;    // byte offset of dst4 inside the signal's block
                 const int lim = nvalid * (K >> 1);
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 1
                 if (tg == 123456789)
@@ -372,11 +364,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                         o.y = *reinterpret_cast<const float*>(ob + P0[i] + 8);
                         o.z = *reinterpret_cast<const float*>(ob + P1[i]);
                         o.w = *reinterpret_cast<const float*>(ob + P1[i] + 8);
-                        if (fused) {                         // write-through (sc1): published without an L2 write-back fence
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), sig_rsrc, goff + 1024 * i, 0, 16);
-                        } else {
-                            dst4[64 * i] = o;
-                        }
+                        dst4[64 * i] = o;
                     }
                 }
             } else if (j < nvalid) {
@@ -405,82 +393,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         }
     }
     if (p.mode != kModeStack) return;
-    if (live) {
-        const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
-        const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
-        if (lane == 0) {
-            double* part = p.partials + (b * p.nblk + blk) * 4;
-            if (fused) {
-                __hip_atomic_store(part + 0, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(part + 1, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(part + 2, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(part + 3, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                part[0] = v0; part[1] = v1; part[2] = v2; part[3] = v3;
-            }
-        }
-    }
-    if (!fused) return;                                  // two-pass mode: fsst_stats/normalize kernels follow
-
-    // ---- fused z-score (FSST._stack_real_imag, synchrosqueeze.py:78-85) without a second launch:
-    // every block of a signal publishes its un-normalised tiles (16-byte write-through stores) and
-    // statistics partials (8-byte agent-scope stores), drains them, and takes a ticket; the block
-    // that draws the last ticket acquires and normalises the whole signal in place while the rest
-    // of the grid keeps computing.  Wait-free (nobody spins), placement-independent (guide G16 form
-    // R1: sc1 payload -> vmcnt(0) in every storing wave -> counter; consumer: one agent acquire).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left the CU
-    __syncthreads();
-    int* lds_flag = reinterpret_cast<int*>(smem);        // the A table is no longer needed
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *lds_flag = (old == tiles_per_sig_blocks - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*lds_flag == 0) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    float* stat = smem + 4;                              // mean_re, 1/std_re, mean_im, 1/std_im
-    if (wv == 0) {                                       // same reduction order as fsst_stats_kernel
-        const double* part = p.partials + b * p.nblk * 4;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int i = lane; i < p.nblk; i += 64) { a0 += part[i * 4]; a1 += part[i * 4 + 1]; a2 += part[i * 4 + 2]; a3 += part[i * 4 + 3]; }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        if (lane == 0) {
-            const double cnt = static_cast<double>(K) * static_cast<double>(n);
-            const double mr = a0 / cnt, mi = a2 / cnt;
-            const double vr = (a1 - a0 * mr) / (cnt - 1.0), vi = (a3 - a2 * mi) / (cnt - 1.0);
-            stat[0] = static_cast<float>(mr); stat[1] = 1.0f / static_cast<float>(sqrt(vr));
-            stat[2] = static_cast<float>(mi); stat[3] = 1.0f / static_cast<float>(sqrt(vi));
-        }
-    }
-    __syncthreads();
-    {
-        const float m_re = stat[0], i_re = stat[1], m_im = stat[2], i_im = stat[3];
-        const int C = 2 * K, total = n * C, tid = threadIdx.x;
-        float* base = p.out + b * static_cast<long long>(total);
-        if ((C & 3) == 0) {
-            float4* b4 = reinterpret_cast<float4*>(base);
-            const int tot4 = total >> 2;
-            int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
-            const int dc = static_cast<int>(1024u % static_cast<unsigned>(C));
-#pragma unroll 4
-            for (int i = tid; i < tot4; i += 256) {
-                float4 v = b4[i];
-                v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
-                v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
-                v.z = (c + 2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
-                v.w = (c + 3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
-                b4[i] = v;
-                c += dc;
-                if (c >= C) c -= C;
-            }
-        } else {
-            for (int i = tid; i < total; i += 256) {
-                const int c = i % C;
-                const float v = base[i];
-                base[i] = (c < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
-            }
-        }
+    const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
+    const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
+    if (lane == 0) {
+        double* part = p.partials + (b * p.nblk + blk) * 4;
+        part[0] = v0; part[1] = v1; part[2] = v2; part[3] = v3;
     }
 }
 

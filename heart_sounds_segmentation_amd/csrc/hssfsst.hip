@@ -120,7 +120,6 @@ struct hssfsst_plan {
     float* d_atab = nullptr;      // nwin == 128: MFMA A-operand constants [32][64]
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
-    int* d_counters = nullptr;    size_t counters_cap = 0;   // ints (1 per signal): fused z-score tickets
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
     int timing = 0;
@@ -151,14 +150,14 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
     return 0;
 }
 
-int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int* counters, int n, int64_t batch, int nblk, hipStream_t st)
+int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int64_t batch, int nblk, hipStream_t st)
 {
     const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     hssfsst::Core128Params cp;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
-    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk; cp.counters = counters;
+    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk;
     auto kern = hssfsst::fsst_core128_kernel<kFpw128>;
     if (lds > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -316,7 +315,6 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_stats) (void)hipFree(p->d_stats);
-    if (p->d_counters) (void)hipFree(p->d_counters);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
@@ -404,7 +402,6 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
     {
         if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * 4, sizeof(double))) != 0) return rc;
         if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
-        if ((rc = grow(reinterpret_cast<void**>(&p->d_counters), &p->counters_cap, static_cast<size_t>(batch), sizeof(int))) != 0) return rc;
     }
 
     hssfsst::CoreParams cp;
@@ -427,6 +424,11 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
     // (tools/chunk_sweep.sh): the overlap LOSES -- the saturating sweep back-pressures the core's own
     // stores (core 0.25 -> 0.32-0.41 ms per 1024 windows) -- and keeping a chunk inside the 256 MiB
     // Infinity Cache does not speed the sweep up either, so the default is k = 1.
+    // Also measured and rejected (git history): fusing the z-score into the
+    // core launch -- "last ticket normalises the signal" (write-through stores + one agent acquire:
+    // 0.62 ms; with an L2 write-back release per block: 0.99 ms) and "blocks of a signal wait for each
+    // other, then normalise their own tiles" (bounded spin + fix-up kernel: 0.58 ms) -- both
+    // bit-identical to, and slower than, the two-pass 0.37 ms per 1024 windows.
     const int64_t per = static_cast<int64_t>(n) * ofps;
     int64_t nchunks = 1;
     if (p->mode == HSSFSST_MODE_STACK) {
@@ -434,16 +436,6 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         if (ce && std::atoi(ce) > 0) nchunks = std::atoi(ce);
         if (nchunks > batch) nchunks = batch;
     }
-    // Experimental fused z-score (nwin = 128 kernel, HSSFSST_FUSED_ZSCORE=1): the last-arriving block
-    // of a signal normalises it in place inside the core launch (ticket + write-through stores + one
-    // agent acquire).  Bit-identical to the two-pass path (tools/fused_check.py, tests), but measured
-    // SLOWER on MI355X: 0.62 ms vs 0.37 ms per 1024 windows (0.99 ms with an L2 write-back release
-    // fence per block) -- one block streaming a whole signal from a loaded chip is latency-bound --
-    // so it stays off by default.
-    static const int fused_env = std::getenv("HSSFSST_FUSED_ZSCORE") ? std::atoi(std::getenv("HSSFSST_FUSED_ZSCORE")) : 0;
-    const bool fused = use128 && p->mode == HSSFSST_MODE_STACK && fused_env != 0 && nchunks == 1 &&
-                       (p->K % 2 == 0) && p->K <= 24 && static_cast<long long>(n) * 2 * p->K * 4 < 0x7fffffffLL;
-    if (fused) HIP_TRY(hipMemsetAsync(p->d_counters, 0, static_cast<size_t>(batch) * sizeof(int), st));
     const int64_t chunk = (batch + nchunks - 1) / nchunks;
     const bool piped = nchunks > 1;
     if (piped) {
@@ -466,7 +458,7 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         if (use128) {
-            rc = launch_core128(p, cx, cout, cp.partials, fused ? p->d_counters + c0 : nullptr, n, cb, nblk, st);
+            rc = launch_core128(p, cx, cout, cp.partials, n, cb, nblk, st);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
@@ -477,7 +469,7 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         }
         if (rc != 0) return rc;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
-        if (p->mode == HSSFSST_MODE_STACK && !fused) {
+        if (p->mode == HSSFSST_MODE_STACK) {
             hipStream_t zs = st;
             if (piped) {
                 HIP_TRY(hipEventRecord(p->sync_ev[ci], st));
