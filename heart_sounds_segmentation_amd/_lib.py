@@ -66,6 +66,10 @@ def lib():
         L.hssfsst_plan_info.restype = c_int
         L.hssfsst_exec.argtypes = [vp, vp, c_i64, c_int, c_int, vp, c_int, vp]
         L.hssfsst_exec.restype = c_int
+        L.hssfsst_exec_cols.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, c_int, vp, c_int, vp]
+        L.hssfsst_exec_cols.restype = c_int
+        L.hssfsst_normalize_running.argtypes = [vp, vp, c_i64, c_int, vp, vp]
+        L.hssfsst_normalize_running.restype = c_int
         L.hssfsst_plan_set_timing.argtypes = [vp, c_int]
         L.hssfsst_plan_set_timing.restype = c_int
         L.hssfsst_plan_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ip]

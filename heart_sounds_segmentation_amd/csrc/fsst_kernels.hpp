@@ -46,6 +46,8 @@ struct CoreParams {
     int K;                // kept rows
     int mode;
     int nblk;             // tiles per signal
+    int col0;             // first output column (frame centre) of every signal
+    int ncols;            // number of output columns (== n for a whole-signal transform)
 };
 
 // Window tables are read-only for the whole launch and indexed wave-uniformly: the constant
@@ -271,8 +273,9 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const int tid = threadIdx.x;
     const int blk = blockIdx.x % p.nblk;
     const long long b = blockIdx.x / p.nblk;
-    const int t0 = blk * TILE;
+    const int t0 = p.col0 + blk * TILE;
     const int n = p.n;
+    const int ncols = p.ncols, tr0 = t0 - p.col0;      // output rows are relative to col0
     const int K = p.K;
     const float* xsig = p.x + b * static_cast<long long>(n);
 
@@ -304,19 +307,19 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     __syncthreads();
     float* acc = own;
 
-    const int valid = min(TILE, n - t0);
+    const int valid = min(TILE, p.col0 + ncols - t0);
     if (p.mode == kModeRaw) {
         // complex64 [K][n], frequency-major: lane tid owns sample t0 + tid
         if (tid < valid) {
-            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(n) + t0 + tid;
+            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr0 + tid;
             for (int k = 0; k < K; ++k)
-                dst[static_cast<long long>(k) * n] = make_float2(acc[k * LD + tid], acc[(K + k) * LD + tid]);
+                dst[static_cast<long long>(k) * ncols] = make_float2(acc[k * LD + tid], acc[(K + k) * LD + tid]);
         }
         return;
     }
     // time-major outputs: the tile's block of `valid * C` floats is contiguous in HBM
     const int C = (p.mode == kModeAbs) ? K : 2 * K;
-    float* dst = p.out + (b * static_cast<long long>(n) + t0) * C;
+    float* dst = p.out + (b * static_cast<long long>(ncols) + tr0) * C;
     const int total = valid * C;
     int tt = tid / C, c = tid - tt * C;
     const int dtt = TILE / C, dc = TILE - dtt * C;
@@ -462,6 +465,18 @@ __global__ __launch_bounds__(256) void fsst_moments_merge_kernel(const float* fe
         st[1] = mean_a + delta * (nb / nn);
         st[2] = m2_a + m2_b + delta * delta * (na * nb / nn);
     }
+}
+
+// Running-moments normalisation (streaming): stats[b] from the {count, mean, M2} state of
+// fsst_moments_merge_kernel, i.e. mean and unbiased std of everything seen so far.
+__global__ __launch_bounds__(64) void fsst_stats_from_state_kernel(const double* state, float4* stats, int nsig)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nsig) return;
+    const double* st = state + static_cast<long long>(b) * 6;
+    const double vr = st[2] / (st[0] - 1.0), vi = st[5] / (st[3] - 1.0);
+    stats[b] = make_float4(static_cast<float>(st[1]), 1.0f / static_cast<float>(sqrt(vr)),
+                           static_cast<float>(st[4]), 1.0f / static_cast<float>(sqrt(vi)));
 }
 
 }  // namespace hssfsst

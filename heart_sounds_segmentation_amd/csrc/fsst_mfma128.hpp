@@ -44,6 +44,8 @@ struct Core128Params {
     int K;
     int mode;
     int nblk;             // wave tiles per signal
+    int col0;             // first output column (frame centre) of every signal
+    int ncols;            // number of output columns (== n for a whole-signal transform)
 };
 
 // cos / sin of 2*pi*j/16, j = 0..7
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
         atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
     const bool live = blk < p.nblk;
-    const int t0 = blk * FPW;
+    const int t0 = p.col0 + blk * FPW;
+    const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     const float* xsig = p.x + b * static_cast<long long>(n);
     if (live) {
         for (int i = lane; i < FPW + 127; i += 64) {     // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
@@ -264,7 +267,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
 
     for (int grp = 0; grp < FPW / 16; ++grp) {
         const int tg = t0 + grp * 16;
-        if (tg >= n) break;
+        if (tg >= cend) break;
+        const int tr = tg - p.col0;
         const float* xb = xs + grp * 16 + lane;
         // keep the per-lane class ids opaque inside the loop: otherwise LICM hoists every
         // "rA + 8 s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
@@ -311,16 +315,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
         const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
-        const int nvalid = min(16, n - tg);
+        const int nvalid = min(16, cend - tg);
         const int koff = klo - 8 * s0;
         if (p.mode == kModeRaw) {
-            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(n) + tg;
+            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
             for (int e = lane; e < K * 16; e += 64) {
                 const int k = e >> 4, jj = e & 15;
                 if (jj < nvalid) {
                     f2 v = own_base[jj * OLD + koff + k];
                     if (wdirty) v += disp_base[jj * LDF + k];
-                    dst[static_cast<long long>(k) * n + jj] = make_float2(v.x, v.y);
+                    dst[static_cast<long long>(k) * ncols + jj] = make_float2(v.x, v.y);
                 }
             }
         } else {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                 // (2) the group's nvalid x 2K floats are contiguous in HBM: 16-byte stores, lane-linear.
                 //     Each float4 = two adjacent (re,re) or (im,im) pairs of one frame row.
                 const char* ob = reinterpret_cast<const char*>(own_base);
-                float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(n) + tg) * C) + lane;
+                float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane;
                 const int lim = nvalid * (K >> 1);
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 1
                 if (tg == 123456789)
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                     }
                 }
             } else if (j < nvalid) {
-                float* dst = p.out + (b * static_cast<long long>(n) + tg + j) * C + g;
+                float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j) * C + g;
                 const bool isabs = (p.mode == kModeAbs);
                 float* dsti = dst + K;
                 for (int i = 0; i < steps; ++i) {

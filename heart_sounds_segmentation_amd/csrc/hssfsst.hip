@@ -150,14 +150,15 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
     return 0;
 }
 
-int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int64_t batch, int nblk, hipStream_t st)
+int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int col0, int ncols,
+                   int64_t batch, int nblk, hipStream_t st)
 {
     const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     hssfsst::Core128Params cp;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
-    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk;
+    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols;
     auto kern = hssfsst::fsst_core128_kernel<kFpw128>;
     if (lds > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -374,17 +375,24 @@ int hssfsst_plan_timing(hssfsst_plan* p, float ms_sum[2], int* nexec)
 int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on_device,
                  float* out, int out_on_device, void* stream)
 {
-    if (!p || !x || !out || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d)", static_cast<long long>(batch), n);
+    return hssfsst_exec_cols(p, x, batch, n, 0, n, x_on_device, out, out_on_device, stream);
+}
+
+int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int col0, int ncols, int x_on_device,
+                      float* out, int out_on_device, void* stream)
+{
+    if (!p || !x || !out || batch < 0 || n < 1 || col0 < 0 || ncols < 1 || col0 > n - ncols)
+        return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d col0=%d ncols=%d)", static_cast<long long>(batch), n, col0, ncols);
     if (batch == 0 || p->K == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(p->device));
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
-    const int nblk = use128 ? (n + kFpw128 - 1) / kFpw128 : (n + kTile - 1) / kTile;
+    const int nblk = use128 ? (ncols + kFpw128 - 1) / kFpw128 : (ncols + kTile - 1) / kTile;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
-    const size_t nx = static_cast<size_t>(batch) * n, no = nx * ofps;
+    const size_t nx = static_cast<size_t>(batch) * n, no = static_cast<size_t>(batch) * ncols * ofps;
 
     const float* dx = x;
     float* dout = out;
@@ -403,10 +411,6 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * 4, sizeof(double))) != 0) return rc;
         if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
     }
-
-    hssfsst::CoreParams cp;
-    cp.x = dx; cp.out = dout; cp.partials = p->d_partials; cp.ctab = p->d_ctab;
-    cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk;
 
     auto next_event = [&](hipEvent_t* out_ev) -> int {
         if (p->ev.size() <= p->ev_used) {
@@ -429,7 +433,7 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
     // 0.62 ms; with an L2 write-back release per block: 0.99 ms) and "blocks of a signal wait for each
     // other, then normalise their own tiles" (bounded spin + fix-up kernel: 0.58 ms) -- both
     // bit-identical to, and slower than, the two-pass 0.37 ms per 1024 windows.
-    const int64_t per = static_cast<int64_t>(n) * ofps;
+    const int64_t per = static_cast<int64_t>(ncols) * ofps;
     int64_t nchunks = 1;
     if (p->mode == HSSFSST_MODE_STACK) {
         const char* ce = std::getenv("HSSFSST_CHUNKS");
@@ -453,12 +457,12 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
         float* cout = dout + c0 * per;
         hssfsst::CoreParams cp;
         cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * 4 : nullptr; cp.ctab = p->d_ctab;
-        cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk;
+        cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols;
         const long long cblocks = static_cast<long long>(cb) * nblk;
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         if (use128) {
-            rc = launch_core128(p, cx, cout, cp.partials, n, cb, nblk, st);
+            rc = launch_core128(p, cx, cout, cp.partials, n, col0, ncols, cb, nblk, st);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
@@ -478,12 +482,12 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
             }
             float4* cstats = reinterpret_cast<float4*>(p->d_stats) + c0;
             hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, zs,
-                               cp.partials, cstats, nblk, n, p->K);
+                               cp.partials, cstats, nblk, ncols, p->K);
             static const int zgrid_env = std::getenv("HSSFSST_ZGRID") ? std::atoi(std::getenv("HSSFSST_ZGRID")) : 0;
             int64_t zgrid = zgrid_env > 0 ? zgrid_env : (piped ? 512 : 4096);
             if (zgrid > cb) zgrid = cb;
             hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, zs,
-                               cout, cstats, n, p->K, static_cast<int>(cb));
+                               cout, cstats, ncols, p->K, static_cast<int>(cb));
             HIP_TRY(hipGetLastError());
         }
     }
@@ -514,6 +518,25 @@ int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, in
     HIP_TRY(hipSetDevice(p->device));
     hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), feats, state, n, p->K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int n, const double* state, void* stream)
+{
+    if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "normalize_running: bad argument");
+    if (batch == 0 || p->K == 0) return 0;
+    if (batch > 0x7fffffffLL || static_cast<long long>(n) * 2 * p->K >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "normalize_running: too large");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float4* stats = reinterpret_cast<float4*>(p->d_stats);
+    hipLaunchKernelGGL(hssfsst::fsst_stats_from_state_kernel, dim3(static_cast<unsigned>((batch + 63) / 64)), dim3(64), 0, st,
+                       state, stats, static_cast<int>(batch));
+    const int64_t zgrid = batch < 4096 ? batch : 4096;
+    hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, st,
+                       feats, stats, n, p->K, static_cast<int>(batch));
     HIP_TRY(hipGetLastError());
     return 0;
 }

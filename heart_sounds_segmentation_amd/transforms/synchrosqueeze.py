@@ -131,10 +131,14 @@ class FSST:
 
     # ------------------------------------------------------------------ execution
     def _run(self, X: torch.Tensor, mode: Optional[int] = None,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """X: (B, n) float32 contiguous, CPU or cuda.  Returns per-mode tensor on X's device."""
-        B, n = X.shape
-        if n < 1:
+             out: Optional[torch.Tensor] = None, cols: Optional[tuple] = None) -> torch.Tensor:
+        """X: (B, n) float32 contiguous, CPU or cuda.  Returns per-mode tensor on X's device.
+        cols = (col0, ncols) restricts the output to those frame centres."""
+        B, n_in = X.shape
+        col0, n = cols if cols is not None else (0, n_in)
+        if col0 < 0 or n < 1 or col0 + n > n_in:
+            raise ValueError(f"FSST: column range ({col0}, {n}) outside a signal of {n_in} samples")
+        if n_in < 1:
             raise ValueError("FSST: empty signal")
         dev = self._device_index(X)
         plan = self._plan(dev, mode)
@@ -156,10 +160,11 @@ class FSST:
         if B == 0 or K == 0:
             return out
         stream = torch.cuda.current_stream(dev).cuda_stream if on_dev else None
-        rc = _lib.lib().hssfsst_exec(plan.handle, ctypes.c_void_p(X.data_ptr()), int(B), int(n),
-                                     1 if on_dev else 0, ctypes.c_void_p(out.data_ptr()),
-                                     1 if on_dev else 0, ctypes.c_void_p(stream) if stream else None)
-        _lib.check(rc, "hssfsst_exec")
+        rc = _lib.lib().hssfsst_exec_cols(plan.handle, ctypes.c_void_p(X.data_ptr()), int(B), int(n_in),
+                                          int(col0), int(n), 1 if on_dev else 0,
+                                          ctypes.c_void_p(out.data_ptr()), 1 if on_dev else 0,
+                                          ctypes.c_void_p(stream) if stream else None)
+        _lib.check(rc, "hssfsst_exec_cols")
         return out
 
     @staticmethod
@@ -214,13 +219,14 @@ class FSST:
                    "hssfsst_plan_timing")
         return float(ms[0]), float(ms[1]), cnt.value
 
-    def unnormalized(self, X: torch.Tensor) -> torch.Tensor:
+    def unnormalized(self, X: torch.Tensor, cols: Optional[tuple] = None) -> torch.Tensor:
         """Extension (streaming): ``(B, n, 2K)`` [real | imag] features
-        WITHOUT the per-signal z-score, for use with running moments."""
+        WITHOUT the per-signal z-score, for use with running moments.  ``cols=(col0, ncols)``
+        computes only those frame centres."""
         X = self._as_f32(X)
         if X.ndim == 1:
             X = X.unsqueeze(0)
-        return self._run(X, _lib.MODE_STACK_UNNORM)
+        return self._run(X, _lib.MODE_STACK_UNNORM, cols=cols)
 
     # ------------------------------------------------------------------ reference helper kept for its contract
     def _truncate_frequencies(self, s: torch.Tensor, f: torch.Tensor):

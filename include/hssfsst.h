@@ -70,6 +70,14 @@ int hssfsst_plan_info(const hssfsst_plan* plan, int* nwin, int* nf, int* klo, in
 int hssfsst_exec(hssfsst_plan* plan, const float* x, int64_t batch, int n, int x_on_device,
                  float* out, int out_on_device, void* stream);
 
+/* Streaming / windowed variant: computes only the output columns (frame centres) col0 .. col0+ncols-1
+ * of every signal; `out` then holds batch * ncols * out_floats_per_sample floats and the STACK
+ * statistics run over those columns.  hssfsst_exec(...) == hssfsst_exec_cols(..., 0, n, ...).
+ * With col0 >= nwin/2 and col0 + ncols <= n - nwin/2 + 1 no frame touches the zero padding, which is
+ * what a rolling transform over a ring buffer needs (SURVEY section 8f row 3 / BASELINE config 5). */
+int hssfsst_exec_cols(hssfsst_plan* plan, const float* x, int64_t batch, int n, int col0, int ncols,
+                      int x_on_device, float* out, int out_on_device, void* stream);
+
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
  * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the
@@ -97,6 +105,11 @@ double hssfsst_update_variance(double x, double m, double var, int64_t k);
  * [batch][n][2K] un-normalised [real | imag] features on the device. */
 int hssfsst_moments_merge(hssfsst_plan* plan, const float* feats, int64_t batch, int n,
                           double* state, void* stream);
+
+/* Streaming z-score: normalises un-normalised features IN PLACE with the running statistics in
+ * `state` (as maintained by hssfsst_moments_merge): (v - mean) / sqrt(M2 / (count - 1)) per block. */
+int hssfsst_normalize_running(hssfsst_plan* plan, float* feats, int64_t batch, int n,
+                              const double* state, void* stream);
 
 int hssfsst_device_count(void);
 int hssfsst_version(void);

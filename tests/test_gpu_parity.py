@@ -306,3 +306,55 @@ def test_kernel_variants_agree(tmp_path):
         colerr = np.abs(g - ref[k]).reshape(ref[k].shape[0], -1)
         # different kernels => different fp32 rounding; allow isolated tie flips (<= 0.1 % of cells)
         assert (colerr > parity.TOL * scale).mean() < 1e-3, ("generic", k, colerr.max(), scale)
+
+
+def test_column_range_equals_full_transform():
+    """hssfsst_exec_cols: a column sub-range equals the same columns of the whole-signal transform
+    (un-normalised features and raw spectrum), for the MFMA kernel (nwin 128) and the generic one."""
+    from scipy.signal import get_window
+    X = torch.from_numpy(synth.noise_windows(3, 1500, seed=12)).cuda()
+    for w, fs in ((KAISER, 1000), (get_window(("kaiser", 0.5), 512, fftbins=False), 4000)):
+        tf = FSST(fs, w, truncate_freq=BAND, stack=True)
+        full = tf.unnormalized(X)
+        for col0, ncols in ((0, 1500), (256, 128), (700, 333), (1499, 1), (64, 1)):
+            part = tf.unnormalized(X, cols=(col0, ncols))
+            assert part.shape == (3, ncols, 44)
+            assert torch.equal(part, full[:, col0:col0 + ncols]), (len(w), col0, ncols)
+    with pytest.raises(ValueError):
+        tf.unnormalized(X, cols=(1400, 200))
+
+
+def test_streaming_matches_offline(oracle_mod):
+    """BASELINE config 5 in miniature: 64 channels at 4 kHz, nwin 512, chunks of 128: the stream's
+    un-normalised columns equal the offline transform (oracle), and the running z-score uses the
+    device moments (== hss.moments recurrences)."""
+    from scipy.signal import get_window
+    from heart_sounds_segmentation_amd.streaming import StreamingFSST
+    fs, N, chunk, ch, steps = 4000, 512, 128, 64, 6
+    w = get_window(("kaiser", 0.5), N, fftbins=False)
+    x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=3)
+    st = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=False)
+    outs = [st.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda()) for i in range(steps)]
+    stream = torch.cat(outs, dim=1).cpu().numpy()                      # (ch, steps*chunk, 44)
+    assert stream.shape == (ch, chunk * steps, 44) and st.latency_samples == 255
+    # offline columns tau = 0 .. T - N/2 are stream columns tau + N/2 - 1
+    off = FSST(fs, w, truncate_freq=BAND, stack=True).unnormalized(torch.from_numpy(x).cuda()).cpu().numpy()
+    T = chunk * steps
+    assert np.array_equal(stream[:, N // 2 - 1:], off[:, : T - N // 2 + 1])
+    # oracle on 2 channels (un-normalised [real | imag] = raw spectrum transposed)
+    for c in (0, 63):
+        s, f, t, hd = oracle_mod.fsst(x[c], fs, w, return_halfdist=True)
+        klo, K = oracle_mod.band(N, fs, *BAND)
+        ref = np.concatenate([s[klo:klo + K].real.T, s[klo:klo + K].imag.T], axis=1).astype(np.float32)
+        parity.check(off[c], ref, hd, 0, what=f"stream ch{c}", frag_budget=0.1)
+    # running normalisation == z-score with the statistics of everything seen so far
+    st2 = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True)
+    seen = []
+    for i in range(3):
+        y = st2.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda())
+        seen.append(outs[i])
+        allre = torch.cat(seen, dim=1)[..., :22].double()
+        m = allre.mean(dim=(1, 2), keepdim=True)
+        sd = allre.flatten(1).std(dim=1, unbiased=True)[:, None, None]
+        want = ((outs[i][..., :22].double() - m) / sd).float()
+        assert (y[..., :22] - want).abs().max() < 2e-4 * want.abs().max()
