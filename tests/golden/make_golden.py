@@ -120,6 +120,20 @@ def main():
                         m2s=np.asarray(m2s))
     print("moments final", means[-1], m2s[-1] / 63, xs.mean(), xs.var(ddof=1))
 
+    # consumer of the features (hss/model/segmenter.py:5-87) at a reduced hidden size: weights, the
+    # non-persistent random h0/c0, an input and the reference module's output (eval mode)
+    ref_seg = _load("ref_segmenter", os.path.join(REF, "hss/model/segmenter.py"))
+    torch.manual_seed(1234)
+    m = ref_seg.HeartSoundSegmenter(input_size=44, batch_size=3, hidden_size=12)
+    m.eval()
+    xin = torch.randn(3, 40, 44)
+    with torch.no_grad():
+        yout = m(xin)
+    seg = {f"sd__{k}": v.numpy() for k, v in m.state_dict().items()}
+    seg.update(h0=m.h0.numpy(), c0=m.c0.numpy(), x=xin.numpy(), y=yout.numpy())
+    np.savez_compressed(os.path.join(HERE, "segmenter.npz"), **seg)
+    print("segmenter", sorted(m.state_dict().keys())[:3], yout.shape)
+
 
 if __name__ == "__main__":
     main()

@@ -358,3 +358,27 @@ def test_streaming_matches_offline(oracle_mod):
         sd = allre.flatten(1).std(dim=1, unbiased=True)[:, None, None]
         want = ((outs[i][..., :22].double() - m) / sd).float()
         assert (y[..., :22] - want).abs().max() < 2e-4 * want.abs().max()
+
+
+def test_corpus_builder_and_end_to_end(oracle_mod):
+    """the batched dataset builder yields what the reference's loop would
+    (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,
+    short recordings skipped) and the features feed the BiLSTM consumer (BASELINE config 4)."""
+    from heart_sounds_segmentation_amd.consumer import SegmenterHead, segment
+    from heart_sounds_segmentation_amd.corpus import build_features
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    recs = [(torch.from_numpy(synth.recording(35000, seed=s)), torch.randint(1, 5, (35000,))) for s in (1, 2)]
+    recs.append((torch.zeros(1500), torch.ones(1500, dtype=torch.int64)))          # skipped (< 2000)
+    items = build_features(recs, tf)
+    assert len(items) == 66                                         # test/test_dataset.py:37 (33 per recording)
+    x0, y0 = items[34]
+    assert x0.shape == (2000, 44) and x0.dtype == torch.float32 and y0.shape == (2000,) and y0.dtype == torch.int64
+    assert int(y0.min()) >= 0 and int(y0.max()) <= 3
+    assert torch.equal(y0, recs[1][1][1000:3000] - 1)               # frame 1 of recording 2
+    ref, hd = oracle_mod.features(recs[1][0][1000:3000].numpy()[None], 1000, KAISER, BAND, "stack", return_halfdist=True)
+    parity.check(x0.numpy(), ref[0], hd[0], 0, what="corpus item")
+    head = SegmenterHead(44, 16, 5).cuda().eval()
+    with torch.no_grad():
+        lp = segment(tf, head, torch.from_numpy(synth.pcg_windows(5, 2000)).cuda())
+    assert lp.shape == (5, 2000, 4) and torch.isfinite(lp).all()
+    assert (lp.exp().sum(-1) - 1).abs().max() < 1e-4

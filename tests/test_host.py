@@ -90,3 +90,19 @@ def test_frame_signal_golden_contract():
     x = torch.arange(35500, dtype=torch.float32)
     F = framing.frame_batch(x, 1000, 2000)
     assert F.shape == (33, 2000) and F[5, 0] == 5000 and F[32, -1] == 33999
+
+
+def test_consumer_matches_reference_segmenter_golden():
+    """tests/golden/segmenter.npz was produced by the reference's HeartSoundSegmenter
+    (hss/model/segmenter.py:5-87): same state_dict keys load, same output."""
+    import os
+    from heart_sounds_segmentation_amd.consumer import SegmenterHead
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "segmenter.npz"))
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd__")}
+    head = SegmenterHead(44, 12, 3, h0=torch.from_numpy(g["h0"]), c0=torch.from_numpy(g["c0"]))
+    missing, unexpected = head.load_state_dict(sd, strict=True), None
+    head.eval()
+    with torch.no_grad():
+        y = head(torch.from_numpy(g["x"]))
+    assert y.shape == (3, 40, 4)
+    assert np.abs(y.numpy() - g["y"]).max() < 1e-5
