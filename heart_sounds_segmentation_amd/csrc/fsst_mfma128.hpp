@@ -7,10 +7,13 @@
 // constants cost SALU issue slots.  So this kernel
 //   * runs the one dense contraction of the path -- the window multiply fused with the first
 //     radix-8 decimation-in-frequency stage,  y_r[n] = sum_{q<8} x[t+n+16q] * C_r[n,q]  (a constant
-//     16 x 8 real matrix applied at every tap n, for 16 frames at a time) -- on the fp32 matrix
-//     pipe (v_mfma_f32_16x16x4_f32, bit-exact fp32 FMA chain), which is otherwise idle and runs
-//     concurrently with the VALU; the constant operand lives in 32 VGPRs for the kernel's lifetime,
-//     the frame operand is one contiguous ds_read_b32 per MFMA (hop-1 frames are shifted copies);
+//     16 x 8 real matrix applied at every tap n, for 16 frames at a time) -- as 32
+//     v_mfma_f32_16x16x4_f32 per 16 frames (bit-exact fp32 FMA chain).  Measured
+//     (profiles/r01_mfma_valu_overlap_ubench.txt): on this chip MFMA time does NOT hide behind VALU
+//     time of the same SIMD, so the gain is not concurrency but issue economy: 32 instructions
+//     instead of 256 v_pk_fma_f32 + their constant-operand traffic for the same ALU time; the
+//     constants come from a shared 8 kB LDS table (one ds_read_b64 per tap), the frame operand is
+//     one contiguous ds_read2_b32 per tap (hop-1 frames are shifted copies);
 //   * finishes with two 16-point FFTs per lane written in packed (re,im) math: 74 v_pk ops each;
 //   * 4 lanes per frame: lane group g = lane>>4 owns bin classes {g, 8-g} ({0,4} for g = 0), so a
 //     bin k = 8j + r and its conjugate partner 128 - k are always in the same lane (two-for-one
@@ -195,8 +198,7 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2* own_slot, bool st
 // ------------------------------------------------------------------------------------------------
 // grid = batch * ceil(nblk / 4) blocks of 4 waves; each WAVE owns a tile of FPW consecutive frames of
 // one signal and walks it in groups of 16 frames, independently of its sibling waves (no block
-// barrier after the prologue, so the waves drift apart and one wave's MFMA phase overlaps
-// another's VALU phase on the same SIMD).
+// barrier after the prologue).
 // LDS: atab[16 taps][64 lanes][2] (shared, 8 KB) | per wave: xs[FPW+127] | own | disp.
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
