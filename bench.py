@@ -23,6 +23,18 @@ BYTES_PER_WINDOW = 2000 * 4 + 2000 * 44 * 4      # 8 000 read + 352
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per core-kernel launch from the committed PMC pass of this same command
+    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as the
+    MI355X guide prescribes).  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return int(json.load(fh)["fsst_core128_kernel"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(X, w, budget_s=12.0):
     """The oracle ("port" of the reference CPU path: fp64 fsst + wrapper epilogue) on the host
     cores of this box, OpenMP over windows, on a bounded sample of the same workload."""
@@ -140,7 +152,8 @@ def main():
                        "windows_per_gpu": B, "parallelism": f"window-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "fsst_core128_kernel<64>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": pmc_traffic() if B == 1024 else None,
                          "algorithmic_bytes_per_launch": BYTES_PER_WINDOW * B,
                          "avg_launch_ms": round(core_ms / max(ncalls, 1), 4),
                          "normalize_avg_launch_ms": round(norm_ms / max(ncalls, 1), 4),

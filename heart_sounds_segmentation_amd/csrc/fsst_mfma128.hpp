@@ -132,6 +132,7 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kWavesPerBlock = 4;
+constexpr int kThrFloats = 64;
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
 {
     return ((fpw + 127 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K) + plane_ldf(K)) + 4;   // + dirty flag
@@ -176,11 +177,14 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // P = Z[128 - k'] (Z = FFT of x (w + i dw') / 2 with the sign (-1)^k' folded into the constants):
 //   V = X + conj(P) = (-1)^k' V[k'],   Vd' = (X - conj(P)) / i,   shift = -Im(Vd'/V) = num / den.
 // The source stays in its own row iff |shift| < 1/2 iff |num| < den/2 (no division); V == 0
-// contributes nothing wherever it lands.  Only when some lane of the wave has a displaced cell does
-// the wave run the exact rounding path for those lanes.
+// contributes nothing wherever it lands.  `thr` (per lane group, from a small LDS table) is 1/2 for
+// kept rows and, for rows outside the kept band, the distance to the band minus 1/2: a smaller move
+// cannot bring the source -- or its negative-frequency mirror -- into a kept row, so it is ignored.
+// Only when some lane of the wave has a cell that may change the output does the wave run the
+// exact rounding path for those lanes.
 template <int S>
-__device__ __forceinline__ void process_source(f2 X, f2 P, f2* own_slot, bool store, f2* row_disp, int* flag,
-                                               int klo, int K, int r)
+__device__ __forceinline__ void process_source(f2 X, f2 P, float thr, f2* own_slot, bool store, f2* row_disp,
+                                               int* flag, int klo, int K, int r)
 {
     const f2 V = add_conj(X, P);
     const f2 Vd = unpack_vd(X, P);
@@ -189,7 +193,7 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2* own_slot, bool st
     const float den = sq.x + sq.y;
     const float num = cr.x - cr.y;
     if (store) *own_slot = V;                           // wave-uniform predicate
-    const bool moved = fabsf(num) >= fmaxf(0.5f * den, 1.0e-37f);
+    const bool moved = fabsf(num) >= fmaxf(thr * den, 1.0e-37f);
     if (__ballot(moved) != 0ull) {
         if (moved) displaced_source(row_disp, flag, klo, K, r + 8 * S, num, den, V);
     }
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     const int blk = (blockIdx.x % tiles_per_sig_blocks) * kWavesPerBlock + wv;
 
     f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
-    float* wbase = smem + 2 * 16 * 64 + wv * wave_lds_floats(FPW, klo, K);
+    float* thrtab = smem + 2 * 16 * 64;                                      // [(s*2 + ab)][4 lane groups], s = 0..7
+    float* wbase = smem + 2 * 16 * 64 + kThrFloats + wv * wave_lds_floats(FPW, klo, K);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
@@ -228,6 +233,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
     for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
         atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
+    if (threadIdx.x < 64) {                              // thresholds: entry (s, ab, group)
+        const int i = threadIdx.x, gg = i & 3, ab = (i >> 2) & 1, s = i >> 3;
+        const int r = ab ? ((gg == 0) ? 4 : 8 - gg) : gg;
+        const int slot = 8 * s + r - klo;
+        const int d = max(slot - (K - 1), -slot);        // > 0: row outside the kept band, d rows away
+        thrtab[i] = (d > 0) ? static_cast<float>(d) - 0.5f : 0.5f;
+    }
     const bool live = blk < p.nblk;
     const int t0 = p.col0 + blk * FPW;
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     f2* ownB = own_base + j * OLD + rB - 8 * s0;
     f2* row_disp = disp_base + j * LDF;
     const f2* myA = atab + lane;
+    const float* mythr = thrtab + g;
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
@@ -307,8 +320,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
             const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
             const bool st = (s >= s0) && (s <= s1);
-            process_source<s>(za[s], PA, ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
-            process_source<s>(zb[s], PB, ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
+            process_source<s>(za[s], PA, mythr[(s * 2 + 0) * 4], ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
+            process_source<s>(zb[s], PB, mythr[(s * 2 + 1) * 4], ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
         });
         // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
         if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
