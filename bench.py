@@ -81,13 +81,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("HSS_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
+    torch.cuda.set_device(local)
+    if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                timeout=datetime.timedelta(seconds=300))
     dev = torch.device("cuda", local)
 
     n, B = 2000, args.batch
@@ -99,7 +101,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -114,29 +116,31 @@ def main():
     elapsed = time.perf_counter() - t0
     core_ms, norm_ms, ncalls = tf.timing(local)
     tf.set_timing(False, local)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # optional exchange step, timed on its own: all-gather of the per-rank feature blocks
     gather = None
-    if world > 1:
-        full = hdist.all_gather_blocks(out, B * world)          # warm-up (allocates, builds rings)
-        sync_all()
-        g0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            full = hdist.all_gather_blocks(out, B * world)
-        sync_all()
-        g = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=dev)
-        dist.all_reduce(g, op=dist.ReduceOp.MAX)
-        gms = float(g.item()) * 1e3
-        step_ms = elapsed / args.steps * 1e3
-        gather = {"allgather_ms": round(gms, 3), "bytes_per_rank": B * n * 44 * 4,
-                  "value_with_allgather": round(B * world / ((step_ms + gms) * 1e-3), 1)}
-        del full
-
+    if use_dist:
+        try:
+            full = hdist.all_gather_blocks(out, B * world)          # warm-up (allocates, builds rings)
+            sync_all()
+            g0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                full = hdist.all_gather_blocks(out, B * world)
+            sync_all()
+            g = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gms = float(g.item()) * 1e3
+            step_ms = elapsed / args.steps * 1e3
+            gather = {"allgather_ms": round(gms, 3), "bytes_per_rank": B * n * 44 * 4,
+                      "value_with_allgather": round(B * world / ((step_ms + gms) * 1e-3), 1)}
+            del full
+        except Exception as e:                                   # never lose the bench line to the side measurement
+            gather = {"error": f"{type(e).__name__}: {e}"[:200]}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
@@ -164,7 +168,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Xh, w, args.cpu_budget)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
