@@ -84,6 +84,8 @@ def lib():
         L.hssfsst_update_variance.restype = c_dbl
         L.hssfsst_moments_merge.argtypes = [vp, vp, c_i64, c_int, vp, vp]
         L.hssfsst_moments_merge.restype = c_int
+        L.hssfsst_parse_signal_csv.argtypes = [ctypes.c_char_p, c_i64, vp, vp, c_i64]
+        L.hssfsst_parse_signal_csv.restype = c_i64
         L.hssfsst_device_count.restype = c_int
         L.hssfsst_version.restype = c_int
         L.hssfsst_last_error.restype = ctypes.c_char_p

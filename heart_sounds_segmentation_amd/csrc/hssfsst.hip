@@ -522,6 +522,35 @@ int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, in
     return 0;
 }
 
+int64_t hssfsst_parse_signal_csv(const char* text, int64_t len, float* signals, int64_t* labels, int64_t cap)
+{
+    if (!text || len < 0 || cap < 0 || (cap > 0 && (!signals || !labels))) return fail(HSSFSST_EINVAL, "parse_signal_csv: bad argument");
+    const char* p = text;
+    const char* end = text + len;
+    while (p < end && *p != '\n') ++p;                  // skiprows=1
+    if (p < end) ++p;
+    int64_t rows = 0;
+    while (p < end) {
+        const char* eol = p;
+        while (eol < end && *eol != '\n') ++eol;
+        const char* q = p;
+        while (q < eol && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
+        if (q < eol) {                                  // non-empty line
+            char* stop = nullptr;
+            const double sig = std::strtod(q, &stop);
+            if (stop == q || stop >= eol || *stop != ',')
+                return fail(HSSFSST_EINVAL, "parse_signal_csv: malformed row %lld", static_cast<long long>(rows + 2));
+            const char* l0 = stop + 1;
+            const double lab = std::strtod(l0, &stop);
+            if (stop == l0) return fail(HSSFSST_EINVAL, "parse_signal_csv: malformed label in row %lld", static_cast<long long>(rows + 2));
+            if (rows < cap) { signals[rows] = static_cast<float>(sig); labels[rows] = static_cast<int64_t>(lab); }
+            ++rows;
+        }
+        p = (eol < end) ? eol + 1 : end;
+    }
+    return rows;
+}
+
 int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int n, const double* state, void* stream)
 {
     if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "normalize_running: bad argument");

@@ -111,6 +111,14 @@ int hssfsst_moments_merge(hssfsst_plan* plan, const float* feats, int64_t batch,
 int hssfsst_normalize_running(hssfsst_plan* plan, float* feats, int64_t batch, int n,
                               const double* state, void* stream);
 
+/* Host helper, no device needed: parser for the corpus files read by DavidSpringerHSS._load_file
+ * (hss/datasets/heart_sounds.py:193-197: pd.read_csv(skiprows=1, names=["Signals", "Labels"])):
+ * text = the whole file; the first line is skipped; every following non-empty line is
+ * "<float>,<number>" (second column read as a number and truncated to int64, as pandas+torch do for
+ * integral label columns).  Fills at most `cap` rows; returns the number of data rows in the file
+ * (call once with cap = 0 to size the buffers) or a negative status on a malformed line. */
+int64_t hssfsst_parse_signal_csv(const char* text, int64_t len, float* signals, int64_t* labels, int64_t cap);
+
 int hssfsst_device_count(void);
 int hssfsst_version(void);
 const char* hssfsst_last_error(void);

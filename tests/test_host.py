@@ -106,3 +106,30 @@ def test_consumer_matches_reference_segmenter_golden():
         y = head(torch.from_numpy(g["x"]))
     assert y.shape == (3, 40, 4)
     assert np.abs(y.numpy() - g["y"]).max() < 1e-5
+
+
+def test_csv_ingest_matches_pandas(built_lib, tmp_path):
+    """ingest.load_file == the reference's _load_file recipe (heart_sounds.py:193-197) on a synthetic
+    file of the corpus format."""
+    import pandas as pd
+    from heart_sounds_segmentation_amd import ingest, _lib
+    rng = np.random.default_rng(5)
+    T = 5000
+    sig = rng.standard_normal(T) * 0.3
+    lab = rng.integers(1, 5, T)
+    path = tmp_path / "a0001"
+    with open(str(path) + ".csv", "w") as fh:
+        fh.write("Signals,Labels\n")
+        for i, (s, l) in enumerate(zip(sig, lab)):
+            fh.write(f"{s!r},{l}\n" if i % 2 else f"{s:.9e},{l}\n")
+    df = pd.read_csv(str(path) + ".csv", skiprows=1, names=["Signals", "Labels"])
+    x_ref = torch.tensor(df.loc[:, "Signals"].to_numpy(), dtype=torch.float32)
+    y_ref = torch.tensor(df.loc[:, "Labels"].to_numpy(), dtype=torch.int64)
+    x, y = ingest.load_file(str(path))
+    assert x.dtype == torch.float32 and y.dtype == torch.int64 and x.shape == (T,)
+    assert torch.equal(x, x_ref) and torch.equal(y, y_ref)
+    with pytest.raises(ValueError):
+        ingest.parse_csv_bytes(b"Signals,Labels\n0.5;1\n")
+    assert ingest.parse_csv_bytes(b"Signals,Labels\n")[0].numel() == 0
+    x2, y2 = ingest.parse_csv_bytes(b"Signals,Labels\r\n1.5,2.0\r\n\r\n-2e-3,4\n")
+    assert x2.tolist() == [1.5, -0.0020000000949949026] and y2.tolist() == [2, 4]
