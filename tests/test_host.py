@@ -121,7 +121,7 @@ def test_csv_ingest_matches_pandas(built_lib, tmp_path):
     with open(str(path) + ".csv", "w") as fh:
         fh.write("Signals,Labels\n")
         for i, (s, l) in enumerate(zip(sig, lab)):
-            fh.write(f"{s!r},{l}\n" if i % 2 else f"{s:.9e},{l}\n")
+            fh.write(f"{float(s)!r},{int(l)}\n" if i % 2 else f"{float(s):.9e},{int(l)}\n")
     df = pd.read_csv(str(path) + ".csv", skiprows=1, names=["Signals", "Labels"])
     x_ref = torch.tensor(df.loc[:, "Signals"].to_numpy(), dtype=torch.float32)
     y_ref = torch.tensor(df.loc[:, "Labels"].to_numpy(), dtype=torch.int64)
