@@ -194,9 +194,7 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, float thr, f2* own_sl
     const float num = cr.x - cr.y;
     if (store) *own_slot = V;                           // wave-uniform predicate
     const bool moved = fabsf(num) >= fmaxf(thr * den, 1.0e-37f);
-    if (__ballot(moved) != 0ull) {
-        if (moved) displaced_source(row_disp, flag, klo, K, r + 8 * S, num, den, V);
-    }
+    if (moved) displaced_source(row_disp, flag, klo, K, r + 8 * S, num, den, V);   // skipped when no lane moved (execz)
 }
 
 // ------------------------------------------------------------------------------------------------
