@@ -400,3 +400,29 @@ def test_band_shapes_nwin128(oracle_mod, band):
             assert np.abs(got[..., 0] - ref[..., 0]).max() <= parity.TOL * np.abs(ref[..., 0]).max()
             continue
         _run_and_check(oracle_mod, X, 1000, KAISER, band, what=f"band{band}{kw}", **kw)
+
+
+def test_bench_contract_json():
+    """bench.py prints ONE JSON line with the driver's fields, the roofline / cpu_baseline objects,
+    and (1-rank RCCL smoke mode) the all-gather side measurement."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSS_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    res = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-budget", "1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "windows/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and d["value"] > 100 * c["value"] / c["cores"]
+    assert "allgather_ms" in d["allgather"]
