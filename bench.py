@@ -65,8 +65,11 @@ def cpu_baseline(X, w, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed steps run BEFORE the W warm-up steps so the GPU reaches its sustained clocks "
+                         "(a 20 ms burst from idle measures the clock ramp: core kernel 0.236 ms vs 0.205 ms sustained)")
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -105,6 +108,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    for _ in range(max(args.settle_steps, 0)):               # clock ramp from idle, untimed (see --settle-steps)
+        tf.batch(X, out=out)
     for _ in range(args.warmup):
         tf.batch(X, out=out)
     sync_all()
@@ -153,7 +158,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2: {B} x {n} fp32 synthetic PCG windows per GPU, fs=1000, "
                                    "Kaiser(128,0.5), band [25,200] Hz, stack=True -> (2000,44) fp32",
-                       "windows_per_gpu": B, "parallelism": f"window-sharded x{world}, no data-path collective"},
+                       "windows_per_gpu": B, "clock_settle_steps": max(args.settle_steps, 0),
+                       "parallelism": f"window-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "fsst_core128_kernel<64>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -65,13 +65,26 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // hipcc materialises (y, -x)-style operands with v_xor + v_mov instead of using the modifiers.
 // Inputs of these statements are always results of ordinary VALU instructions (never MFMA
 // destinations), so no manual hazard padding is needed inside the strings.
-__device__ __forceinline__ f2 add_conj(f2 x, f2 p)       // x + conj(p)
+// Two-for-one unpack of a source bin X = Z[k'] with conjugate partner P = Z[128 - k'], emitted directly in
+// the operand layout of the packed den/num product below:
+//   V   = X + conj(P)       = (X.x + P.x, X.y - P.y)
+//   Vd' = (X - conj(P)) / i = (X.y + P.y, P.x - X.x)
+__device__ __forceinline__ f2 mix_re(f2 x, f2 p)         // (V.re, Vd'.im) = (p.x + x.x, p.x - x.x)
 {
-    f2 d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p)); return d;
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(x)); return d;
 }
-__device__ __forceinline__ f2 unpack_vd(f2 x, f2 p)      // (x - conj(p)) / i = (x.y + p.y, p.x - x.x)
+__device__ __forceinline__ f2 mix_im(f2 x, f2 p)         // (V.im, Vd'.re) = (x.y - p.y, x.y + p.y)
 {
-    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(x), "v"(p)); return d;
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,1]" : "=v"(d) : "v"(x), "v"(p)); return d;
+}
+// (den, num) = (|V|^2, Vd'.re V.im - Vd'.im V.re) in two packed FMAs: t1 = mix_re, t2 = mix_im
+__device__ __forceinline__ f2 dn_first(f2 t1, f2 c)      // (t1.lo^2, -t1.lo t1.hi) + c
+{
+    f2 d; asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(t1), "s"(c)); return d;
+}
+__device__ __forceinline__ f2 dn_second(f2 t2, f2 m)     // (t2.lo^2, t2.lo t2.hi) + m
+{
+    f2 d; asm("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(t2), "v"(m)); return d;
 }
 __device__ __forceinline__ f2 add_mi(f2 e, f2 o)         // e + (-i) o
 {
@@ -81,11 +94,6 @@ __device__ __forceinline__ f2 sub_mi(f2 e, f2 o)         // e - (-i) o
 {
     f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(e), "v"(o)); return d;
 }
-__device__ __forceinline__ f2 mul_swap(f2 a, f2 b)       // (a.x b.y, a.y b.x)
-{
-    f2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
-}
-
 // Radix-2 DIT butterfly on packed complex values, twiddle W = exp(-2*pi*i*TW/16).
 template <int TW>
 __device__ __forceinline__ void bfly16(f2& e, f2& o)
@@ -132,7 +140,6 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kWavesPerBlock = 4;
-constexpr int kThrFloats = 64;
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
 {
     return ((fpw + 127 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K) + plane_ldf(K)) + 4;   // + dirty flag
@@ -176,25 +183,25 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner
 // P = Z[128 - k'] (Z = FFT of x (w + i dw') / 2 with the sign (-1)^k' folded into the constants):
 //   V = X + conj(P) = (-1)^k' V[k'],   Vd' = (X - conj(P)) / i,   shift = -Im(Vd'/V) = num / den.
-// The source stays in its own row iff |shift| < 1/2 iff |num| < den/2 (no division); V == 0
-// contributes nothing wherever it lands.  `thr` (per lane group, from a small LDS table) is 1/2 for
-// kept rows and, for rows outside the kept band, the distance to the band minus 1/2: a smaller move
-// cannot bring the source -- or its negative-frequency mirror -- into a kept row, so it is ignored.
-// Only when some lane of the wave has a cell that may change the output does the wave run the
-// exact rounding path for those lanes.
+// The source stays in its own row iff |shift| < 1/2 iff |num| < den/2 (no division); den carries +1e-37
+// so that V == 0 (which contributes nothing wherever it lands) never takes the rare path.  V is stored
+// unconditionally into the source's own column; only when some lane of the wave has a displaced cell does
+// the wave run the exact rounding path for it.  (Folding the 1/2 into the constants by doubling dw' saves
+// one more multiply per source, 1 % of the kernel, but doubles the cancellation error of V for far-moving
+// cells: measured 5 instead of 3 rounding flips per 918 k robust Hann columns, so it is not done.)
 template <int S>
-__device__ __forceinline__ void process_source(f2 X, f2 P, float thr, f2* own_slot, bool store, f2* row_disp,
+__device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot, bool store, f2* row_disp,
                                                int* flag, int klo, int K, int r)
 {
-    const f2 V = add_conj(X, P);
-    const f2 Vd = unpack_vd(X, P);
-    const f2 sq = V * V;
-    const f2 cr = mul_swap(Vd, V);
-    const float den = sq.x + sq.y;
-    const float num = cr.x - cr.y;
-    if (store) *own_slot = V;                           // wave-uniform predicate
-    const bool moved = fabsf(num) >= fmaxf(thr * den, 1.0e-37f);
-    if (moved) displaced_source(row_disp, flag, klo, K, r + 8 * S, num, den, V);   // skipped when no lane moved (execz)
+    const f2 t1 = mix_re(X, P);                         // (V.re, Vd'.im)
+    const f2 t2 = mix_im(X, P);                         // (V.im, Vd'.re)
+    const f2 dn = dn_second(t2, dn_first(t1, tiny));    // (den, num)
+    if (store) {                                        // wave-uniform predicate
+        float* q = reinterpret_cast<float*>(own_slot);
+        q[0] = t1.x; q[1] = t2.x;
+    }
+    if (fabsf(dn.y) >= 0.5f * dn.x)                     // skipped when no lane moved (execz)
+        displaced_source(row_disp, flag, klo, K, r + 8 * S, dn.y, dn.x, f2{t1.x, t2.x});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,8 +228,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     const int blk = (blockIdx.x % tiles_per_sig_blocks) * kWavesPerBlock + wv;
 
     f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
-    float* thrtab = smem + 2 * 16 * 64;                                      // [(s*2 + ab)][4 lane groups], s = 0..7
-    float* wbase = smem + 2 * 16 * 64 + kThrFloats + wv * wave_lds_floats(FPW, klo, K);
+    float* wbase = smem + 2 * 16 * 64 + wv * wave_lds_floats(FPW, klo, K);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
@@ -231,13 +237,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
     for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
         atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
-    if (threadIdx.x < 64) {                              // thresholds: entry (s, ab, group)
-        const int i = threadIdx.x, gg = i & 3, ab = (i >> 2) & 1, s = i >> 3;
-        const int r = ab ? ((gg == 0) ? 4 : 8 - gg) : gg;
-        const int slot = 8 * s + r - klo;
-        const int d = max(slot - (K - 1), -slot);        // > 0: row outside the kept band, d rows away
-        thrtab[i] = (d > 0) ? static_cast<float>(d) - 0.5f : 0.5f;
-    }
     const bool live = blk < p.nblk;
     const int t0 = p.col0 + blk * FPW;
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
@@ -259,7 +258,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     f2* ownB = own_base + j * OLD + rB - 8 * s0;
     f2* row_disp = disp_base + j * LDF;
     const f2* myA = atab + lane;
-    const float* mythr = thrtab + g;
+    f2 tiny = {1.0e-37f, 0.0f};
+    asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
             const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
             const bool st = (s >= s0) && (s <= s1);
-            process_source<s>(za[s], PA, mythr[(s * 2 + 0) * 4], ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
-            process_source<s>(zb[s], PB, mythr[(s * 2 + 1) * 4], ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
+            process_source<s>(za[s], PA, tiny, ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
+            process_source<s>(zb[s], PB, tiny, ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
         });
         // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
         if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};

@@ -153,7 +153,7 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
 int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int col0, int ncols,
                    int64_t batch, int nblk, hipStream_t st)
 {
-    const size_t lds = (2 * 16 * 64 + hssfsst::kThrFloats + static_cast<size_t>(hssfsst::kWavesPerBlock) *
+    const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     hssfsst::Core128Params cp;

@@ -1,15 +1,19 @@
 #!/bin/bash
 # usage: bash tools/profile_round.sh <tag>   (on the GPU box, from the repo root)
-# Runs the default bench, a rocprofv3 kernel-trace of the same command and two PMC passes
-# (FETCH_SIZE, WRITE_SIZE separately: they do not fit one pass on gfx950), all into gpurun_out/<tag>/.
+# Runs the default bench, a rocprofv3 kernel-trace of the SAME command (minus the CPU leg) and PMC passes
+# (FETCH_SIZE, WRITE_SIZE separately: they do not fit one pass on gfx950; short runs, counters do not depend
+# on clocks), all into gpurun_out/<tag>/, then writes gpurun_out/<tag>/summary.json (tools/rocprof_summary.py).
 tag=${1:-prof}
 R=$(pwd); O=$R/gpurun_out/$tag; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM -d $O/p1 -o p1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/p1.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES -d $O/p2 -o p2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/p2.log 2>&1
+S="--steps 5 --warmup 1 --settle-steps 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- python bench.py $S > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- python bench.py $S > $O/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM -d $O/p1 -o p1 -- python bench.py $S > $O/p1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES -d $O/p2 -o p2 -- python bench.py $S > $O/p2.log 2>&1
+python tools/rocprof_summary.py $O/summary.json $O/kt/kt_results.db $O/fetch/fetch_results.db $O/write/write_results.db $O/p1/p1_results.db $O/p2/p2_results.db > $O/summary.log 2>&1
+rm -rf $O/kt $O/fetch $O/write $O/p1 $O/p2     # the sqlite files are large; the summary is what travels back
 cat $O/bench.json
