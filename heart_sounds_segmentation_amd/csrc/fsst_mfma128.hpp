@@ -140,6 +140,10 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kWavesPerBlock = 4;
+__host__ __device__ constexpr int core128_blocks_per_signal(int ntiles, int tpw)
+{
+    return ((ntiles + tpw - 1) / tpw + kWavesPerBlock - 1) / kWavesPerBlock;
+}
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
 {
     return ((fpw + 127 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K) + plane_ldf(K)) + 4;   // + dirty flag
@@ -210,7 +214,9 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
 // barrier after the prologue).
 // LDS: atab[16 taps][64 lanes][2] (shared, 8 KB) | per wave: xs[FPW+127] | own | disp.
 // ------------------------------------------------------------------------------------------------
-template <int FPW>
+// FAST: the time-major [re | im] epilogue with 16-byte stores (mode STACK / STACK_UNNORM, K even, K <= 24 -- the
+// canonical configuration); otherwise the general epilogue (raw / abs / any K).  The host picks.
+template <int FPW, bool FAST, int TPW>
 __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_kernel(Core128Params p)
 {
     constexpr int XS = ((FPW + 127 + 3) / 4) * 4;
@@ -223,9 +229,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int tiles_per_sig_blocks = (p.nblk + kWavesPerBlock - 1) / kWavesPerBlock;
-    const long long b = blockIdx.x / tiles_per_sig_blocks;
-    const int blk = (blockIdx.x % tiles_per_sig_blocks) * kWavesPerBlock + wv;
+    const int blocks_per_sig = core128_blocks_per_signal(p.nblk, TPW);
+    const long long b = blockIdx.x / blocks_per_sig;
+    const int blk0 = ((blockIdx.x % blocks_per_sig) * kWavesPerBlock + wv) * TPW;   // first of this wave's TPW tiles
 
     f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
     float* wbase = smem + 2 * 16 * 64 + wv * wave_lds_floats(FPW, klo, K);
@@ -237,15 +243,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
     for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
         atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
-    const bool live = blk < p.nblk;
-    const int t0 = p.col0 + blk * FPW;
+    const bool live = blk0 < p.nblk;
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     const float* xsig = p.x + b * static_cast<long long>(n);
-    if (live) {
-        for (int i = lane; i < FPW + 127; i += 64) {     // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
+    auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
+        for (int i = lane; i < FPW + 127; i += 64) {
             const int gi = t0 + i - 64;
             xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
         }
+    };
+    if (live) {
+        stage_tile(p.col0 + blk0 * FPW);
         for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
         if (lane == 0) *flag = 0;
     }
@@ -263,9 +271,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
-    const bool fast_out = (p.mode == kModeStack || p.mode == kModeStackUnnorm) && ((K & 1) == 0) && (K <= 24);
     int P0[3], P1[3];
-    {
+    if constexpr (FAST) {
         const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
         const int koff0 = klo - 8 * s0;
 #pragma unroll
@@ -278,6 +285,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         }
     }
 
+    for (int tt = 0; tt < TPW; ++tt) {
+    const int blk = blk0 + tt;
+    if (blk >= p.nblk) break;
+    const int t0 = p.col0 + blk * FPW;
+    if (tt > 0) { stage_tile(t0); wave_sync(); }
     for (int grp = 0; grp < FPW / 16; ++grp) {
         const int tg = t0 + grp * 16;
         if (tg >= cend) break;
@@ -299,17 +311,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             za[bitrev4(nn)] = f2{acc.x, acc.y};
             zb[bitrev4(nn)] = f2{acc.z, acc.w};
         });
-#if !defined(HSS_ABLATE) || HSS_ABLATE < 3
         fft16(za);
         fft16(zb);
-#endif
-#if defined(HSS_ABLATE) && HSS_ABLATE >= 2
-        {   // keep the results alive without the source stage
-            f2 acc = {0.0f, 0.0f};
-            static_for<16>([&](auto I) { acc += za[decltype(I)::value] + zb[decltype(I)::value]; });
-            if (s1 >= 0 && isg0) own_base[j * OLD] = acc;
-        }
-#else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
         static_for<8>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
@@ -323,14 +326,60 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         });
         // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
         if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
-#endif
         wave_sync();
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
         const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
         const int nvalid = min(16, cend - tg);
         const int koff = klo - 8 * s0;
-        if (p.mode == kModeRaw) {
+        if constexpr (FAST) {
+            // lane (g, j): frame j, kept rows k = g + 4 u (u < 6 covers K <= 24) as packed (re, im) cells
+            f2* src = own_base + j * OLD + koff + g;
+            if (wdirty) {                                    // (rare) fold the displaced plane into the own plane
+                const f2* dsp = disp_base + j * LDF + g;
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (g + 4 * u < K) src[4 * u] += dsp[4 * u];
+                wave_sync();
+            }
+            if (p.mode == kModeStack) {
+                // statistics: six unconditional cell reads (a row past the band still lies inside this wave's
+                // LDS), then only the one row group that is partial across lanes pays for a select
+                f2 v[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) v[u] = src[4 * u];
+                const int ufull = (nvalid == 16) ? (K >> 2) : 0;     // rows 4u + 3 < K: valid in every lane
+                const bool jv = j < nvalid;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    if (u < ufull) {
+                        st_s += v[u]; st_q = pk_fma(v[u], v[u], st_q);
+                    } else if (4 * u < K) {
+                        const bool ok = jv && (g + 4 * u < K);
+                        const f2 vm = {ok ? v[u].x : 0.0f, ok ? v[u].y : 0.0f};
+                        st_s += vm; st_q = pk_fma(vm, vm, st_q);
+                    }
+                }
+            }
+            // the group's nvalid x 2K floats are contiguous in HBM: 16-byte stores, lane-linear; each float4 =
+            // two adjacent (re,re) or (im,im) pairs of one frame row.  All LDS reads first, then the stores.
+            const int C = 2 * K;
+            const char* ob = reinterpret_cast<const char*>(own_base);
+            float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane;
+            const int lim = nvalid * (K >> 1);
+            f4 o[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                o[i].x = *reinterpret_cast<const float*>(ob + P0[i]);
+                o[i].y = *reinterpret_cast<const float*>(ob + P0[i] + 8);
+                o[i].z = *reinterpret_cast<const float*>(ob + P1[i]);
+                o[i].w = *reinterpret_cast<const float*>(ob + P1[i] + 8);
+            }
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));   // keep the reads ahead of the predicated stores
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (lane + 64 * i < lim) dst4[64 * i] = make_float4(o[i].x, o[i].y, o[i].z, o[i].w);
+        } else if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
             for (int e = lane; e < K * 16; e += 64) {
                 const int k = e >> 4, jj = e & 15;
@@ -340,65 +389,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                     dst[static_cast<long long>(k) * ncols + jj] = make_float2(v.x, v.y);
                 }
             }
-        } else {
+        } else if (j < nvalid) {
             // lane (g, j): frame j, kept rows k = g, g + 4, g + 8 ... as packed (re, im) pairs
             const int C = (p.mode == kModeAbs) ? K : 2 * K;
             const int steps = (K - g + 3) >> 2;              // rows g + 4 i < K
-            f2* src = own_base + j * OLD + koff + g;
+            const f2* src = own_base + j * OLD + koff + g;
             const f2* dsp = disp_base + j * LDF + g;
-            if (fast_out) {
-                // (1) fold the displaced plane into the own plane (rare) and take the statistics
-                if (wdirty || p.mode == kModeStack) {
-                    for (int i0 = 0; i0 < steps; i0 += 6) {
-                        f2 v[6];
-#pragma unroll
-                        for (int u = 0; u < 6; ++u) v[u] = (i0 + u < steps) ? src[4 * (i0 + u)] : f2{0.0f, 0.0f};
-                        if (wdirty) {
-#pragma unroll
-                            for (int u = 0; u < 6; ++u)
-                                if (i0 + u < steps) { v[u] += dsp[4 * (i0 + u)]; src[4 * (i0 + u)] = v[u]; }
-                        }
-                        if (j < nvalid) {
-#pragma unroll
-                            for (int u = 0; u < 6; ++u) { st_s += v[u]; st_q = pk_fma(v[u], v[u], st_q); }
-                        }
-                    }
-                    wave_sync();
-                }
-                // (2) the group's nvalid x 2K floats are contiguous in HBM: 16-byte stores, lane-linear.
-                //     Each float4 = two adjacent (re,re) or (im,im) pairs of one frame row.
-                const char* ob = reinterpret_cast<const char*>(own_base);
-                float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane;
-                const int lim = nvalid * (K >> 1);
-#if defined(HSS_ABLATE) && HSS_ABLATE >= 1
-                if (tg == 123456789)
-#endif
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (lane + 64 * i < lim) {
-                        float4 o;
-                        o.x = *reinterpret_cast<const float*>(ob + P0[i]);
-                        o.y = *reinterpret_cast<const float*>(ob + P0[i] + 8);
-                        o.z = *reinterpret_cast<const float*>(ob + P1[i]);
-                        o.w = *reinterpret_cast<const float*>(ob + P1[i] + 8);
-                        dst4[64 * i] = o;
-                    }
-                }
-            } else if (j < nvalid) {
-                float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j) * C + g;
-                const bool isabs = (p.mode == kModeAbs);
-                float* dsti = dst + K;
-                for (int i = 0; i < steps; ++i) {
-                    f2 v = src[4 * i];
-                    if (wdirty) v += dsp[4 * i];
-                    if (isabs) {
-                        dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
-                    } else {
-                        dst[4 * i] = v.x;
-                        dsti[4 * i] = v.y;
-                        st_s += v;
-                        st_q = pk_fma(v, v, st_q);
-                    }
+            float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j) * C + g;
+            const bool isabs = (p.mode == kModeAbs);
+            float* dsti = dst + K;
+            for (int i = 0; i < steps; ++i) {
+                f2 v = src[4 * i];
+                if (wdirty) v += dsp[4 * i];
+                if (isabs) {
+                    dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+                } else {
+                    dst[4 * i] = v.x;
+                    dsti[4 * i] = v.y;
+                    st_s += v;
+                    st_q = pk_fma(v, v, st_q);
                 }
             }
         }
@@ -409,13 +418,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             wave_sync();
         }
     }
+    }
     if (p.mode != kModeStack) return;
+    // fp32 lane accumulators span this wave's TPW tiles (<= 24 TPW cells each); across lanes and waves fp64
     const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
     const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
-    if (lane == 0) {
-        double* part = p.partials + (b * p.nblk + blk) * 4;
-        part[0] = v0; part[1] = v1; part[2] = v2; part[3] = v3;
-    }
+    // one partial per tile slot is what the statistics kernel sums: this wave's total goes into the slot of
+    // its first tile, zeros into the slots of its other tiles
+    double* part = p.partials + (b * p.nblk + blk0) * 4;
+    const int nslots = min(TPW, p.nblk - blk0) * 4;
+    if (lane < nslots) part[lane] = (lane == 0) ? v0 : (lane == 1) ? v1 : (lane == 2) ? v2 : (lane == 3) ? v3 : 0.0;
 }
 
 }  // namespace hssfsst

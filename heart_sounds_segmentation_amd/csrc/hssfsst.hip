@@ -108,7 +108,14 @@ void band_rows(int nwin, double fs, double f_lo, double f_hi, int* klo, int* K)
 }
 
 constexpr int kTile = 64;
-constexpr int kFpw128 = 64;      // frames per wave tile of the nwin = 128 kernel
+#ifndef HSS_FPW128
+#define HSS_FPW128 64
+#endif
+constexpr int kFpw128 = HSS_FPW128;      // frames per wave tile of the nwin = 128 kernel
+#ifndef HSS_TPW128
+#define HSS_TPW128 2
+#endif
+constexpr int kTpw128 = HSS_TPW128;      // consecutive tiles one wave walks (amortises the per-wave set-up)
 
 }  // namespace
 
@@ -159,11 +166,13 @@ int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double*
     hssfsst::Core128Params cp;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols;
-    auto kern = hssfsst::fsst_core128_kernel<kFpw128>;
+    const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
+                      (pl->K & 1) == 0 && pl->K <= 24;
+    auto kern = fast ? hssfsst::fsst_core128_kernel<kFpw128, true, kTpw128> : hssfsst::fsst_core128_kernel<kFpw128, false, kTpw128>;
     if (lds > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    const int64_t bps = (nblk + hssfsst::kWavesPerBlock - 1) / hssfsst::kWavesPerBlock;
+    const int64_t bps = hssfsst::core128_blocks_per_signal(nblk, kTpw128);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(batch * bps)), dim3(64 * hssfsst::kWavesPerBlock), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
