@@ -36,6 +36,7 @@ namespace hssfsst {
 
 using f2 = float __attribute__((ext_vector_type(2)));
 using f4 = float __attribute__((ext_vector_type(4)));
+using lds_float = __attribute__((address_space(3))) float;
 
 struct Core128Params {
     const float* x;       // [batch][n]
@@ -113,10 +114,12 @@ __device__ __forceinline__ void bfly16(f2& e, f2& o)
 }
 
 // In-place 16-point complex FFT (forward); input in bit-reversed order, output natural order.
+// FIRST = 1 skips the first (twiddle-free) stage, which the caller has already applied.
+template <int FIRST = 0>
 __device__ __forceinline__ void fft16(f2 (&z)[16])
 {
-    static_for<4>([&](auto S) {
-        constexpr int L = 2 << decltype(S)::value;
+    static_for<4 - FIRST>([&](auto S) {
+        constexpr int L = 2 << (decltype(S)::value + FIRST);
         constexpr int H = L / 2;
         constexpr int STEP = 16 / L;
         static_for<8>([&](auto B) {
@@ -140,6 +143,23 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kWavesPerBlock = 4;
+
+// FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
+// float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
+// tab[i][lane] = first pair, tab[3 + i][lane] = second pair; a pair's second element is 8 bytes further.
+inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */)
+{
+    const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
+    const int old = own_ld(klo, K), koff0 = klo - 8 * own_s0(klo);
+    for (int i = 0; i < 3; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int f = lane + 64 * i;
+            const int jj = (f / Q < 15) ? f / Q : 15, c = 4 * (f - (f / Q) * Q);
+            const int rowb = jj * old + koff0;
+            tab[i * 64 + lane] = (c < K) ? (rowb + c) * 8 : (rowb + c - K) * 8 + 4;
+            tab[(3 + i) * 64 + lane] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
+        }
+}
 __host__ __device__ constexpr int core128_blocks_per_signal(int ntiles, int tpw)
 {
     return ((ntiles + tpw - 1) / tpw + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -272,19 +292,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
     int P0[3], P1[3];
-    if constexpr (FAST) {
-        const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
-        const int koff0 = klo - 8 * s0;
+    if constexpr (FAST) {                                // host-made table (core128_store_offsets), after the A table
+        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int f = lane + 64 * i;
-            const int jj = min(f / Q, 15), c = 4 * (f - (f / Q) * Q);
-            const int rowb = jj * OLD + koff0;
-            P0[i] = (c < K) ? (rowb + c) * 8 : (rowb + c - K) * 8 + 4;
-            P1[i] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
-        }
+        for (int i = 0; i < 3; ++i) { P0[i] = ptab[i * 64 + lane]; P1[i] = ptab[(3 + i) * 64 + lane]; }
     }
-
     for (int tt = 0; tt < TPW; ++tt) {
     const int blk = blk0 + tt;
     if (blk >= p.nblk) break;
@@ -294,7 +306,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         const int tg = t0 + grp * 16;
         if (tg >= cend) break;
         const int tr = tg - p.col0;
-        const float* xb = xs + grp * 16 + lane;
+        // the tile's LDS byte address as ONE opaque register: every tap is then an immediate offset of it
+        // (otherwise each merged ds_read2 gets its own "base + 0x2000 + tap" v_add)
+        unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + lane)));
+        asm volatile("" : "+v"(xaddr));
+        const lds_float* xb = (const lds_float*)static_cast<size_t>(xaddr);
         // keep the per-lane class ids opaque inside the loop: otherwise LICM hoists every
         // "rA + 8 s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
         int rAi = rA, rBi = rB;
@@ -302,17 +318,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
 
         // ---- folded window + radix-8 stage on the matrix pipe: 16 taps x 2 k-halves
         f2 za[16], zb[16];
-        static_for<16>([&](auto NN) {
-            constexpr int nn = decltype(NN)::value;
-            const f2 a2 = myA[nn * 64];
-            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, xb[nn], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, xb[nn + 64], acc, 0, 0, 0);
-            za[bitrev4(nn)] = f2{acc.x, acc.y};
-            zb[bitrev4(nn)] = f2{acc.z, acc.w};
+        // four taps at a time: the four first k-halves, then the four second k-halves (the dependent MFMA of a
+        // tap is issued three MFMAs after its first half; measured 1 % faster than tap by tap)
+        static_for<4>([&](auto GG) {
+            constexpr int g0 = decltype(GG)::value * 4;
+            f4 acc[4];
+            f2 a2[4];
+            static_for<4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                a2[i] = myA[(g0 + i) * 64];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i].x, xb[g0 + i], f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i].y, xb[g0 + i + 64], acc[i], 0, 0, 0);
+                za[bitrev4(g0 + i)] = f2{acc[i].x, acc[i].y};
+                zb[bitrev4(g0 + i)] = f2{acc[i].z, acc[i].w};
+            });
         });
+#if !defined(HSS_ABLATE) || HSS_ABLATE < 4
         fft16(za);
         fft16(zb);
+#endif
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 3
+        {   // development only: keep the spectra alive without the source stage
+            f2 acc = {0.0f, 0.0f};
+            static_for<16>([&](auto I) { acc += za[decltype(I)::value] + zb[decltype(I)::value]; });
+            if (s1 >= 0 && isg0) own_base[j * OLD] = acc;
+        }
+#else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
         static_for<8>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
@@ -326,6 +361,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         });
         // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
         if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
+#endif
         wave_sync();
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
@@ -342,6 +378,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
                     if (g + 4 * u < K) src[4 * u] += dsp[4 * u];
                 wave_sync();
             }
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 2
+            if (tg == 123456789)
+#endif
             if (p.mode == kModeStack) {
                 // statistics: six unconditional cell reads (a row past the band still lies inside this wave's
                 // LDS), then only the one row group that is partial across lanes pays for a select
@@ -368,6 +407,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane;
             const int lim = nvalid * (K >> 1);
             f4 o[3];
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 1
+            if (tg == 123456789)
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 o[i].x = *reinterpret_cast<const float*>(ob + P0[i]);
@@ -379,6 +422,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (lane + 64 * i < lim) dst4[64 * i] = make_float4(o[i].x, o[i].y, o[i].z, o[i].w);
+            }
         } else if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
             for (int e = lane; e < K * 16; e += 64) {

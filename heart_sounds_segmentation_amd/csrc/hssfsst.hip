@@ -291,7 +291,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
         // Row i: lane group gg = i >> 2 owns classes ca = gg and cb = (gg ? 8 - gg : 4); sub = i & 3:
         // {ca re, ca im, cb re, cb im}.  Entry = component of
         //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + 16 q] * exp(-2 pi i (r q / 8 + r n / 128)),  q = k + 4 h.
-        std::vector<float> at(32 * 64);
+        std::vector<float> at(32 * 64 + 6 * 64);          // A table, then the FAST epilogue's store offsets (ints)
         for (int n = 0; n < 16; ++n)
             for (int h = 0; h < 2; ++h)
                 for (int l = 0; l < 64; ++l) {
@@ -305,6 +305,12 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                     const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
                     at[(n * 2 + h) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
                 }
+        static_assert(sizeof(int) == sizeof(float), "offset table shares the float buffer");
+        {
+            int offs[6 * 64];
+            hssfsst::core128_store_offsets(p->klo, p->K > 0 ? p->K : 2, offs);
+            std::memcpy(at.data() + 32 * 64, offs, sizeof(offs));
+        }
         e = hipMalloc(reinterpret_cast<void**>(&p->d_atab), at.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
