@@ -38,19 +38,59 @@ using f2 = float __attribute__((ext_vector_type(2)));
 using f4 = float __attribute__((ext_vector_type(4)));
 using lds_float = __attribute__((address_space(3))) float;
 
+// Work distribution: one persistent block of 16 waves per CU.  The launch is cut into CHUNKS of consecutive 16-frame
+// groups of one signal; the chunk list is ordered by region -- all region-0 chunks of all signals (8 groups each),
+// then region 1 (4 groups), then region 2 (2 groups).  Block B owns chunks B, B + grid, B + 2 grid, ... (the same
+// mix of big and small chunks for every CU) and its waves draw them in that order from a counter in LDS, so the 16
+// waves of a CU finish within one small chunk of each other.  Why: the SIMD arbiter favours the oldest wave, so with
+// equal static work per wave the four waves of a SIMD finished at 114 / 125 / 140 / 162 us, and with one fixed chunk
+// per wave and several rounds of 4-wave blocks the last 20 % of the kernel ran at falling occupancy
+// (profiles/r01_block_timeline.txt).  A ticket counter in HBM instead of LDS costs ~4 ns per draw, serialised
+// chip-wide: 23 552 draws made the kernel 0.29 ms.  The chunk pattern of a signal depends only on the number of
+// columns, not on the batch, and every chunk writes its own statistics partial: results are independent of the
+// batch composition and run-to-run deterministic whichever wave processes a chunk.
+struct Core128Regions {
+    int g0[3];            // first 16-frame group of the region (per signal)
+    int gpc[3];           // groups per chunk
+    int npc[3];           // chunks per signal
+};
+
 struct Core128Params {
     const float* x;       // [batch][n]
     float* out;
-    double* partials;     // [batch][nblk][4]
-    const float* atab;    // MFMA A-operand constants [16 taps][2 k-halves][64 lanes]
+    double* partials;     // [batch][slots][4], one slot per chunk of the signal
+    const float* atab;    // MFMA A-operand constants [16 taps][2 k-halves][64 lanes], then the FAST store offsets
     int n;
     int klo;
     int K;
     int mode;
-    int nblk;             // wave tiles per signal
+    int nsig;             // signals in this launch
     int col0;             // first output column (frame centre) of every signal
     int ncols;            // number of output columns (== n for a whole-signal transform)
+    Core128Regions reg;
 };
+
+// Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
+// quarter or so, then 2-group chunks at the very end (each chunk costs a ticket, a tile staging and a statistics
+// reduction, so the small ones are kept to the tail).
+inline Core128Regions core128_regions(int ngroups)
+{
+    Core128Regions r{};
+    const int tail2 = ngroups >= 32 ? 6 : 0;             // groups wanted as 2-group chunks
+    const int tail4 = ngroups >= 32 ? 16 : 0;            // groups wanted as 4-group chunks
+    int big = ngroups - tail2 - tail4;
+    big -= big % 8;                                      // whole 8-group chunks only
+    if (big < 0) big = 0;
+    int mid = ngroups - big - tail2;
+    if (tail2 > 0) mid -= mid % 4;                       // whole 4-group chunks; the remainder joins the 2-group tail
+    const int rest = ngroups - big - mid;
+    r.g0[0] = 0;          r.gpc[0] = 8; r.npc[0] = big / 8;
+    r.g0[1] = big;        r.gpc[1] = 4; r.npc[1] = (mid + 3) / 4;
+    r.g0[2] = big + mid;  r.gpc[2] = 2; r.npc[2] = (rest + 1) / 2;
+    return r;
+}
+__host__ __device__ inline int core128_chunks_per_signal(const Core128Regions& r) { return r.npc[0] + r.npc[1] + r.npc[2]; }
+
 
 // cos / sin of 2*pi*j/16, j = 0..7
 __device__ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508978f,
@@ -142,7 +182,8 @@ __host__ __device__ constexpr int plane_ldf(int K) { return odd_up(K); }
 __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
-constexpr int kWavesPerBlock = 4;
+constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
+constexpr int kCtlFloats = 4;                // block control words in LDS (chunk counter)
 
 // FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
 // float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
@@ -159,10 +200,6 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */)
             tab[i * 64 + lane] = (c < K) ? (rowb + c) * 8 : (rowb + c - K) * 8 + 4;
             tab[(3 + i) * 64 + lane] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
         }
-}
-__host__ __device__ constexpr int core128_blocks_per_signal(int ntiles, int tpw)
-{
-    return ((ntiles + tpw - 1) / tpw + kWavesPerBlock - 1) / kWavesPerBlock;
 }
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
 {
@@ -236,8 +273,9 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
 // ------------------------------------------------------------------------------------------------
 // FAST: the time-major [re | im] epilogue with 16-byte stores (mode STACK / STACK_UNNORM, K even, K <= 24 -- the
 // canonical configuration); otherwise the general epilogue (raw / abs / any K).  The host picks.
-template <int FPW, bool FAST, int TPW>
-__global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_kernel(Core128Params p)
+// WPB: waves per block -- 16 (a whole CU) whenever 16 wave regions fit the 160 KB of LDS, else 8 / 4 / 2 / 1.
+template <int FPW, bool FAST, int WPB>
+__global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core128Params p)
 {
     constexpr int XS = ((FPW + 127 + 3) / 4) * 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -249,37 +287,39 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int blocks_per_sig = core128_blocks_per_signal(p.nblk, TPW);
-    const long long b = blockIdx.x / blocks_per_sig;
-    const int blk0 = ((blockIdx.x % blocks_per_sig) * kWavesPerBlock + wv) * TPW;   // first of this wave's TPW tiles
-
+#ifdef HSS_CLOCKPROBE
+    const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
+#endif
     f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
-    float* wbase = smem + 2 * 16 * 64 + wv * wave_lds_floats(FPW, klo, K);
+    int* next_q = reinterpret_cast<int*>(smem + 2 * 16 * 64);               // block's chunk counter
+    float* wbase = smem + 2 * 16 * 64 + kCtlFloats + wv * wave_lds_floats(FPW, klo, K);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
 
     // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
-    for (int i = threadIdx.x; i < 16 * 64; i += 64 * kWavesPerBlock)
+    for (int i = threadIdx.x; i < 16 * 64; i += 64 * WPB)
         atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
-    const bool live = blk0 < p.nblk;
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
-    const float* xsig = p.x + b * static_cast<long long>(n);
-    auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
-        for (int i = lane; i < FPW + 127; i += 64) {
-            const int gi = t0 + i - 64;
-            xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
-        }
-    };
-    if (live) {
-        stage_tile(p.col0 + blk0 * FPW);
-        for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-        if (lane == 0) *flag = 0;
-    }
+    for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+    if (lane == 0) *flag = 0;
+    if (threadIdx.x == 0) *next_q = 0;
     __syncthreads();
-    if (!live) return;
 
+    // chunk bookkeeping (wave-uniform)
+    const int nc0 = p.nsig * p.reg.npc[0];               // (the host keeps nsig * chunks per signal below 2^31)
+    const int nc1 = nc0 + p.nsig * p.reg.npc[1];
+    const int nchunks = nc1 + p.nsig * p.reg.npc[2];
+    const int ngroups = (ncols + 15) >> 4;
+    auto draw = [&]() -> int {                           // next chunk of this block, or nchunks when it has none left
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q = __builtin_amdgcn_readfirstlane(q);
+        const long long c = static_cast<long long>(blockIdx.x) + static_cast<long long>(q) * gridDim.x;
+        return c < nchunks ? static_cast<int>(c) : nchunks;
+    };
+    int chunk = draw();
     const bool isg0 = (g == 0);
     const int rA = g, rB = isg0 ? 4 : 8 - g;
     f2* ownA = own_base + j * OLD + rA - 8 * s0;         // column of k' = 8 s + rA at + 8 s
@@ -288,7 +328,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
     const f2* myA = atab + lane;
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
-    f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
     int P0[3], P1[3];
@@ -297,14 +336,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
 #pragma unroll
         for (int i = 0; i < 3; ++i) { P0[i] = ptab[i * 64 + lane]; P1[i] = ptab[(3 + i) * 64 + lane]; }
     }
-    for (int tt = 0; tt < TPW; ++tt) {
-    const int blk = blk0 + tt;
-    if (blk >= p.nblk) break;
-    const int t0 = p.col0 + blk * FPW;
-    if (tt > 0) { stage_tile(t0); wave_sync(); }
-    for (int grp = 0; grp < FPW / 16; ++grp) {
+    while (chunk < nchunks) {
+    // decode: region, signal, first group, number of groups, statistics slot
+    const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
+    const int local = chunk - ((rg == 0) ? 0 : (rg == 1) ? nc0 : nc1);
+    const int npc = p.reg.npc[rg], gpc = p.reg.gpc[rg];
+    const long long b = local / npc;
+    const int cidx = local - static_cast<int>(b) * npc;
+    const int grp0 = p.reg.g0[rg] + cidx * gpc;
+    const int ngrp = min(gpc, ngroups - grp0);
+    const int slot = ((rg > 0) ? p.reg.npc[0] : 0) + ((rg > 1) ? p.reg.npc[1] : 0) + cidx;
+    const float* xsig = p.x + b * static_cast<long long>(n);
+    auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
+        for (int i = lane; i < FPW + 127; i += 64) {
+            const int gi = t0 + i - 64;
+            xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+        }
+    };
+    f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2) of this chunk
+    for (int sub = 0; sub < ngrp; sub += FPW / 16) {
+    const int t0 = p.col0 + (grp0 + sub) * 16;
+    stage_tile(t0);
+    wave_sync();
+    const int gend = min(FPW / 16, ngrp - sub);
+    for (int grp = 0; grp < gend; ++grp) {
         const int tg = t0 + grp * 16;
-        if (tg >= cend) break;
         const int tr = tg - p.col0;
         // the tile's LDS byte address as ONE opaque register: every tap is then an immediate offset of it
         // (otherwise each merged ds_read2 gets its own "base + 0x2000 + tap" v_add)
@@ -338,8 +394,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             });
         });
 #if !defined(HSS_ABLATE) || HSS_ABLATE < 4
+#ifdef HSS_ASM_STAGE1
+        // First (twiddle-free) FFT stage in packed math, straight on the MFMA results.  The compiler emits these 32
+        // butterfly outputs as 64 scalar adds (it extracts the accumulator lanes one by one); a VALU instruction
+        // that reads a matrix-pipe result costs about twice a normal one (profiles/r01_mfma_rate_ubench.txt, V13 vs
+        // V7), so 32 packed instructions are worth forcing.  Inline asm is invisible to the compiler's MFMA->VALU
+        // hazard padding, hence the fixed order: nothing crosses the scheduling barrier, and the butterflies of
+        // taps 0-3 / 8-11 (whose MFMAs are at least 8 matrix instructions old) go first, so the first read of a
+        // result of the last MFMA group comes 16 VALU instructions after it was issued (required: 11 wait states).
+        __builtin_amdgcn_sched_barrier(0);
+        auto bfly0 = [&](f2& e, f2& o) {
+            f2 a, b;
+            asm volatile("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"
+                         : "=&v"(a), "=&v"(b) : "v"(e), "v"(o));
+            e = a; o = b;
+        };
+        static_for<8>([&](auto NN) {
+            constexpr int e = bitrev4(decltype(NN)::value);   // taps nn and nn + 8 sit in slots e and e + 1
+            bfly0(za[e], za[e + 1]);
+            bfly0(zb[e], zb[e + 1]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fft16<1>(za);
+        fft16<1>(zb);
+#else
         fft16(za);
         fft16(zb);
+#endif
 #endif
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 3
         {   // development only: keep the spectra alive without the source stage
@@ -421,7 +502,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
             asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));   // keep the reads ahead of the predicated stores
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (lane + 64 * i < lim) dst4[64 * i] = make_float4(o[i].x, o[i].y, o[i].z, o[i].w);
+                // streaming stores: the features are not read again by this kernel, and lines left dirty in L2 by
+                // 256 CUs that all write until the last microsecond cost ~10 us of write-back after the kernel
+                if (lane + 64 * i < lim) __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
             }
         } else if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
@@ -463,15 +546,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, HSS_MW128) void fsst_core128_k
         }
     }
     }
-    if (p.mode != kModeStack) return;
-    // fp32 lane accumulators span this wave's TPW tiles (<= 24 TPW cells each); across lanes and waves fp64
-    const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
-    const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
-    // one partial per tile slot is what the statistics kernel sums: this wave's total goes into the slot of
-    // its first tile, zeros into the slots of its other tiles
-    double* part = p.partials + (b * p.nblk + blk0) * 4;
-    const int nslots = min(TPW, p.nblk - blk0) * 4;
-    if (lane < nslots) part[lane] = (lane == 0) ? v0 : (lane == 1) ? v1 : (lane == 2) ? v2 : (lane == 3) ? v3 : 0.0;
+    if (p.mode == kModeStack) {
+        // one partial per chunk: fp32 per lane over the chunk (<= 48 cells), fp64 across lanes, chunks and signals
+        const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
+        const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
+        double* part = p.partials + (b * core128_chunks_per_signal(p.reg) + slot) * 4;
+        if (lane < 4) part[lane] = (lane == 0) ? v0 : (lane == 1) ? v1 : (lane == 2) ? v2 : v3;
+    }
+    chunk = draw();
+    }
+#ifdef HSS_CLOCKPROBE
+    // development only (STACK_UNNORM, tools/clock_probe.py): HSS_CLOCKPROBE=1 -- shader-clock ticks and 100 MHz ticks one
+    // wave in the middle of the grid lived; =2 -- start / end time (100 MHz ticks, low 32 bits) of every block's wave 0
+    if (HSS_CLOCKPROBE == 1 && blockIdx.x == gridDim.x / 2 && wv == 0 && lane == 0) {
+        p.out[0] = static_cast<float>(__builtin_readcyclecounter() - probe_c0);
+        p.out[1] = static_cast<float>(wall_clock64() - probe_r0);
+    }
+    if (HSS_CLOCKPROBE == 2 && wv == 0 && lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(p.out) + 2 * static_cast<size_t>(blockIdx.x);
+        o[0] = static_cast<unsigned>(probe_r0); o[1] = static_cast<unsigned>(wall_clock64());
+    }
+#endif
 }
 
 }  // namespace hssfsst

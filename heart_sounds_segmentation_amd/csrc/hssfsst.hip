@@ -112,10 +112,6 @@ constexpr int kTile = 64;
 #define HSS_FPW128 64
 #endif
 constexpr int kFpw128 = HSS_FPW128;      // frames per wave tile of the nwin = 128 kernel
-#ifndef HSS_TPW128
-#define HSS_TPW128 2
-#endif
-constexpr int kTpw128 = HSS_TPW128;      // consecutive tiles one wave walks (amortises the per-wave set-up)
 
 }  // namespace
 
@@ -126,6 +122,7 @@ struct hssfsst_plan {
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
     float* d_atab = nullptr;      // nwin == 128: MFMA A-operand constants [32][64]
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
+    int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
@@ -157,25 +154,50 @@ int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long
     return 0;
 }
 
-int launch_core128(const hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int col0, int ncols,
-                   int64_t batch, int nblk, hipStream_t st)
+template <bool FAST, int WPB>
+int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
-    const size_t lds = (2 * 16 * 64 + static_cast<size_t>(hssfsst::kWavesPerBlock) *
+    const size_t lds = (2 * 16 * 64 + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
-    if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
-    hssfsst::Core128Params cp;
-    cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
-    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols;
-    const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
-                      (pl->K & 1) == 0 && pl->K <= 24;
-    auto kern = fast ? hssfsst::fsst_core128_kernel<kFpw128, true, kTpw128> : hssfsst::fsst_core128_kernel<kFpw128, false, kTpw128>;
-    if (lds > 32 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    const int64_t bps = hssfsst::core128_blocks_per_signal(nblk, kTpw128);
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(batch * bps)), dim3(64 * hssfsst::kWavesPerBlock), lds, st, cp);
+    auto kern = hssfsst::fsst_core128_kernel<kFpw128, FAST, WPB>;
+    if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
+        if (lds > 32 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        if (per_cu < 1) per_cu = 1;
+        if (cus < 1) cus = 1;
+        pl->core128_slots = per_cu * cus;
+    }
+    int64_t blocks = nchunks;                            // small launches: one chunk per block, spread over the CUs
+    if (blocks > pl->core128_slots) blocks = pl->core128_slots;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int col0, int ncols,
+                   int64_t batch, hipStream_t st)
+{
+    hssfsst::Core128Params cp;
+    cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
+    cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = static_cast<int>(batch);
+    cp.col0 = col0; cp.ncols = ncols;
+    cp.reg = hssfsst::core128_regions((ncols + 15) / 16);
+    const int64_t nchunks = batch * hssfsst::core128_chunks_per_signal(cp.reg);
+    const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
+                      (pl->K & 1) == 0 && pl->K <= 24;
+    // waves per block: as many wave regions as fit the 160 KiB of LDS beside the shared tables
+    const size_t fixed = (2 * 16 * 64 + hssfsst::kCtlFloats) * sizeof(float);
+    const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
+    const size_t room = 160 * 1024;
+    if (fast) return launch_core128_wpb<true, 16>(pl, cp, nchunks, st);       // K <= 24: 16 regions always fit
+    if (fixed + 16 * per_wave <= room) return launch_core128_wpb<false, 16>(pl, cp, nchunks, st);
+    if (fixed + 8 * per_wave <= room) return launch_core128_wpb<false, 8>(pl, cp, nchunks, st);
+    if (fixed + 4 * per_wave <= room) return launch_core128_wpb<false, 4>(pl, cp, nchunks, st);
+    return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B per wave exceeds the 160 KiB budget", per_wave);
 }
 
 int grow(void** ptr, size_t* cap, size_t need, size_t elem)
@@ -403,7 +425,9 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
     HIP_TRY(hipSetDevice(p->device));
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
-    const int nblk = use128 ? (ncols + kFpw128 - 1) / kFpw128 : (ncols + kTile - 1) / kTile;
+    // statistics partials per signal: one per chunk (nwin 128) / per 64-frame tile (generic kernel)
+    const int nblk = use128 ? hssfsst::core128_chunks_per_signal(hssfsst::core128_regions((ncols + 15) / 16))
+                            : (ncols + kTile - 1) / kTile;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
@@ -477,7 +501,7 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         if (use128) {
-            rc = launch_core128(p, cx, cout, cp.partials, n, col0, ncols, cb, nblk, st);
+            rc = launch_core128(p, cx, cout, cp.partials, n, col0, ncols, cb, st);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;

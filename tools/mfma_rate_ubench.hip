@@ -83,6 +83,22 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tot += f2{acc[i].x, acc[i].y}; tot += f2{acc[i].z, acc[i].w}; }
         }
+    } else if (V == 13) {                                 // V10 with the fold spread over 8 independent chains (like V7, but reading the accumulators)
+        f4 acc[16]; f2 q[8];
+        for (int i = 0; i < 16; ++i) acc[i] = f4{seed, seed, seed, seed};
+        for (int i = 0; i < 8; ++i) q[i] = f2{seed + i, seed - i};
+        const float a = seed + lane, b = seed - lane;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { q[i & 7] += f2{acc[i].x, acc[i].y}; q[(i + 4) & 7] += f2{acc[i].z, acc[i].w}; }
+        }
+        for (int i = 0; i < 8; ++i) tot += q[i];
     } else if (V == 10) {                                 // V3 (persistent accumulators) + fold that reads them every iteration
         f4 acc[16];
         for (int i = 0; i < 16; ++i) acc[i] = f4{seed, seed, seed, seed};
@@ -180,6 +196,7 @@ int main()
     run<7>("V7 = V3 + 32 unrelated v_pk_add", d, dc, 125);
     run<9>("V9 = V5 with srcC = zero VGPRs", d, dc, 125);
     run<10>("V10 = V3 + fold reading the accumulators", d, dc, 125);
+    run<13>("V13 = V10, fold over 8 independent chains", d, dc, 125);
     run<3>("V3 again", d, dc, 125);
     run<5>("V5 again", d, dc, 125);
     run<6>("V6 again", d, dc, 125);
