@@ -389,14 +389,37 @@ __global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, 
 
 // grid = any number of blocks of 256 (the host sizes it to a fraction of the chip so the sweep can
 // share the GPU with a concurrently running core kernel); block b handles signals b, b + grid, ...
-__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, int n, int K,
-                                                             int nsignals)
+// With `partials` != nullptr the block first reduces the signal's nblk fp64 partials itself (the arithmetic of
+// fsst_stats_kernel, same order, same result) instead of reading `stats`: one launch less per transform.
+__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, const double* partials,
+                                                             int nblk, int n, int K, int nsignals)
 {
+    __shared__ float4 st_sh;
     const int tid = threadIdx.x;
     const int C = 2 * K;
     const int total = n * C;                             // per-signal element count (< 2^31, checked on the host)
     for (int sig = blockIdx.x; sig < nsignals; sig += gridDim.x) {
-        const float4 st = stats[sig];
+        float4 st;
+        if (partials != nullptr) {
+            if (tid < 64) {
+                const double* part = partials + static_cast<long long>(sig) * nblk * 4;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int i = tid; i < nblk; i += 64) { a0 += part[i * 4]; a1 += part[i * 4 + 1]; a2 += part[i * 4 + 2]; a3 += part[i * 4 + 3]; }
+                a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+                if (tid == 0) {
+                    const double cnt = static_cast<double>(K) * static_cast<double>(n);
+                    const double mr = a0 / cnt, mi = a2 / cnt;
+                    const double vr = (a1 - a0 * mr) / (cnt - 1.0), vi = (a3 - a2 * mi) / (cnt - 1.0);
+                    st_sh = make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
+                                        static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
+                }
+            }
+            __syncthreads();
+            st = st_sh;
+            __syncthreads();                             // st_sh is rewritten for the block's next signal
+        } else {
+            st = stats[sig];
+        }
         const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
         float* base = out + static_cast<long long>(sig) * total;
         if ((C & 3) == 0) {

@@ -25,6 +25,7 @@
 // is the same as in fsst_kernels.hpp and follows oracle/fsst_oracle.c steps 4-7.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "fsst_kernels.hpp"
 
@@ -557,13 +558,13 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     }
 #ifdef HSS_CLOCKPROBE
     // development only (STACK_UNNORM, tools/clock_probe.py): HSS_CLOCKPROBE=1 -- shader-clock ticks and 100 MHz ticks one
-    // wave in the middle of the grid lived; =2 -- start / end time (100 MHz ticks, low 32 bits) of every block's wave 0
+    // wave in the middle of the grid lived; =2 -- start / end time (100 MHz ticks, low 32 bits) of every wave
     if (HSS_CLOCKPROBE == 1 && blockIdx.x == gridDim.x / 2 && wv == 0 && lane == 0) {
         p.out[0] = static_cast<float>(__builtin_readcyclecounter() - probe_c0);
         p.out[1] = static_cast<float>(wall_clock64() - probe_r0);
     }
-    if (HSS_CLOCKPROBE == 2 && wv == 0 && lane == 0) {
-        unsigned* o = reinterpret_cast<unsigned*>(p.out) + 2 * static_cast<size_t>(blockIdx.x);
+    if (HSS_CLOCKPROBE == 2 && lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(p.out) + 2 * (static_cast<size_t>(blockIdx.x) * WPB + wv);
         o[0] = static_cast<unsigned>(probe_r0); o[1] = static_cast<unsigned>(wall_clock64());
     }
 #endif

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Block residency timeline of the nwin=128 core (library built with -DHSS_CLOCKPROBE=2).  usage: block_timeline.py lib.so"""
+"""Wave residency timeline of the nwin=128 core (library built with -DHSS_CLOCKPROBE=2): one record per wave.
+usage: [NBLOCKS=4096 BY_RANK=1 BY_XCD=1] block_timeline.py lib.so   (NBLOCKS = number of wave records = grid * waves per block)"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,13 +18,13 @@ torch.cuda.synchronize()
 t = out.view(torch.int32).flatten()[: 2 * nblocks].cpu().numpy().astype(np.int64).reshape(-1, 2) & 0xffffffff
 ok = (t[:, 1] >= t[:, 0]) & (t[:, 1] - t[:, 0] < 100000)
 t = t[ok]; t0 = t[:, 0].min(); s = (t[:, 0] - t0) / 100.0; e = (t[:, 1] - t0) / 100.0      # microseconds
-print(f"{ok.sum()} of {nblocks} block records usable; kernel span {e.max():.1f} us; block life median {np.median(e - s):.1f} us "
+print(f"{ok.sum()} of {nblocks} wave records usable; kernel span {e.max():.1f} us; wave life median {np.median(e - s):.1f} us "
       f"(p5 {np.percentile(e - s, 5):.1f}, p95 {np.percentile(e - s, 95):.1f})")
 edges = np.arange(0, e.max() + 10, 10.0)
 for a in edges[:-1]:
     resident = ((s < a + 10) & (e > a)).sum()
     mid = ((s <= a + 5) & (e > a + 5)).sum()
-    print(f"t = {a:5.0f}..{a + 10:5.0f} us: blocks resident at the midpoint {mid:5d} (capacity 1024), started in the slice {((s >= a) & (s < a + 10)).sum():5d}")
+    print(f"t = {a:5.0f}..{a + 10:5.0f} us: waves resident at the midpoint {mid:5d} (capacity 4096), started in the slice {((s >= a) & (s < a + 10)).sum():5d}")
 if os.environ.get("BY_XCD"):
     life = (e - s)
     idx = np.nonzero(ok)[0]
