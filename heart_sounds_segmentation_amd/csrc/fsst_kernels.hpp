@@ -391,14 +391,17 @@ __global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, 
 // share the GPU with a concurrently running core kernel); block b handles signals b, b + grid, ...
 // With `partials` != nullptr the block first reduces the signal's nblk fp64 partials itself (the arithmetic of
 // fsst_stats_kernel, same order, same result) instead of reading `stats`: one launch less per transform.
+// `slices` > 1 cuts every signal into that many contiguous pieces, one block each (small batches: a block per
+// signal would leave most of the chip idle); the fused reduction is only used with slices == 1.
 __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, const double* partials,
-                                                             int nblk, int n, int K, int nsignals)
+                                                             int nblk, int n, int K, int nsignals, int slices)
 {
     __shared__ float4 st_sh;
     const int tid = threadIdx.x;
     const int C = 2 * K;
     const int total = n * C;                             // per-signal element count (< 2^31, checked on the host)
-    for (int sig = blockIdx.x; sig < nsignals; sig += gridDim.x) {
+    for (int unit = blockIdx.x; unit < nsignals * slices; unit += gridDim.x) {
+        const int sig = unit / slices, sl = unit - sig * slices;
         float4 st;
         if (partials != nullptr) {
             if (tid < 64) {
@@ -427,10 +430,12 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
             // incrementally (no integer division in the loop)
             float4* b4 = reinterpret_cast<float4*>(base);
             const int tot4 = total >> 2;
-            int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
+            const int i0 = static_cast<int>(static_cast<long long>(tot4) * sl / slices);
+            const int i1 = static_cast<int>(static_cast<long long>(tot4) * (sl + 1) / slices);
+            int c = static_cast<int>((static_cast<unsigned>(i0 + tid) * 4u) % static_cast<unsigned>(C));
             const int dc = static_cast<int>(1024u % static_cast<unsigned>(C));
 #pragma unroll 4
-            for (int i = tid; i < tot4; i += 256) {
+            for (int i = i0 + tid; i < i1; i += 256) {
                 float4 v = b4[i];
                 v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
                 v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
@@ -441,7 +446,9 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
                 if (c >= C) c -= C;
             }
         } else {
-            for (int i = tid; i < total; i += 256) {
+            const int i0 = static_cast<int>(static_cast<long long>(total) * sl / slices);
+            const int i1 = static_cast<int>(static_cast<long long>(total) * (sl + 1) / slices);
+            for (int i = i0 + tid; i < i1; i += 256) {
                 const int c = i % C;
                 const float v = base[i];
                 base[i] = (c < K) ? (v - m_re) * i_re : (v - m_im) * i_im;

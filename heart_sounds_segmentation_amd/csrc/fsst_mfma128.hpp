@@ -184,7 +184,7 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
-constexpr int kCtlFloats = 4;                // block control words in LDS (chunk counter)
+constexpr int kCtlFloats = 4 + 6 * 64;       // block control words in LDS: chunk counter, FAST store-offset table
 
 // FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
 // float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
@@ -306,6 +306,11 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane == 0) *flag = 0;
     if (threadIdx.x == 0) *next_q = 0;
+    if constexpr (FAST) {
+        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
+        int* dstp = reinterpret_cast<int*>(smem + 2 * 16 * 64 + 4);
+        for (int i = threadIdx.x; i < 6 * 64; i += 64 * WPB) dstp[i] = ptab[i];
+    }
     __syncthreads();
 
     // chunk bookkeeping (wave-uniform)
@@ -331,12 +336,9 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
-    int P0[3], P1[3];
-    if constexpr (FAST) {                                // host-made table (core128_store_offsets), after the A table
-        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { P0[i] = ptab[i * 64 + lane]; P1[i] = ptab[(3 + i) * 64 + lane]; }
-    }
+    // (the host-made offset table, core128_store_offsets, sits in LDS and is re-read per group: 6 ds_read instead
+    //  of 6 VGPRs pinned through the whole kernel, which is what pushed the register allocation into scratch)
+    const int* ptab_lds = reinterpret_cast<const int*>(smem + 2 * 16 * 64 + 4) + lane;
     while (chunk < nchunks) {
     // decode: region, signal, first group, number of groups, statistics slot
     const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
@@ -355,6 +357,11 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         }
     };
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};        // (sum re, sum im), (sum re^2, sum im^2) of this chunk
+    // opaque copies of the lane coordinates for the HBM addressing below: otherwise the per-lane 64-bit address
+    // parts are hoisted out of the chunk loop, held in registers across it and spilled to scratch (a kernel with
+    // scratch costs isolated launches ~200 us on this runtime)
+    int lane_o = lane, g_o = g, j_o = j;
+    asm volatile("" : "+v"(lane_o), "+v"(g_o), "+v"(j_o));
     for (int sub = 0; sub < ngrp; sub += FPW / 16) {
     const int t0 = p.col0 + (grp0 + sub) * 16;
     stage_tile(t0);
@@ -451,6 +458,10 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         const int nvalid = min(16, cend - tg);
         const int koff = klo - 8 * s0;
         if constexpr (FAST) {
+            // this lane's store offsets for the group (read here, used after the statistics: latency hidden)
+            int pofs[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pofs[i] = ptab_lds[i * 64];
             // lane (g, j): frame j, kept rows k = g + 4 u (u < 6 covers K <= 24) as packed (re, im) cells
             f2* src = own_base + j * OLD + koff + g;
             if (wdirty) {                                    // (rare) fold the displaced plane into the own plane
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             // two adjacent (re,re) or (im,im) pairs of one frame row.  All LDS reads first, then the stores.
             const int C = 2 * K;
             const char* ob = reinterpret_cast<const char*>(own_base);
-            float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane;
+            float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + tr) * C) + lane_o;
             const int lim = nvalid * (K >> 1);
             f4 o[3];
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 1
@@ -495,10 +506,11 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                o[i].x = *reinterpret_cast<const float*>(ob + P0[i]);
-                o[i].y = *reinterpret_cast<const float*>(ob + P0[i] + 8);
-                o[i].z = *reinterpret_cast<const float*>(ob + P1[i]);
-                o[i].w = *reinterpret_cast<const float*>(ob + P1[i] + 8);
+                const int p0 = pofs[i], p1 = pofs[3 + i];
+                o[i].x = *reinterpret_cast<const float*>(ob + p0);
+                o[i].y = *reinterpret_cast<const float*>(ob + p0 + 8);
+                o[i].z = *reinterpret_cast<const float*>(ob + p1);
+                o[i].w = *reinterpret_cast<const float*>(ob + p1 + 8);
             }
             asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));   // keep the reads ahead of the predicated stores
 #pragma unroll
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             }
         } else if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
-            for (int e = lane; e < K * 16; e += 64) {
+            for (int e = lane_o; e < K * 16; e += 64) {
                 const int k = e >> 4, jj = e & 15;
                 if (jj < nvalid) {
                     f2 v = own_base[jj * OLD + koff + k];
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             const int steps = (K - g + 3) >> 2;              // rows g + 4 i < K
             const f2* src = own_base + j * OLD + koff + g;
             const f2* dsp = disp_base + j * LDF + g;
-            float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j) * C + g;
+            float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j_o) * C + g_o;
             const bool isabs = (p.mode == kModeAbs);
             float* dsti = dst + K;
             for (int i = 0; i < steps; ++i) {
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         const double v0 = wave_sum(static_cast<double>(st_s.x)), v1 = wave_sum(static_cast<double>(st_q.x));
         const double v2 = wave_sum(static_cast<double>(st_s.y)), v3 = wave_sum(static_cast<double>(st_q.y));
         double* part = p.partials + (b * core128_chunks_per_signal(p.reg) + slot) * 4;
-        if (lane < 4) part[lane] = (lane == 0) ? v0 : (lane == 1) ? v1 : (lane == 2) ? v2 : v3;
+        if (lane_o < 4) part[lane_o] = (lane_o == 0) ? v0 : (lane_o == 1) ? v1 : (lane_o == 2) ? v2 : v3;
     }
     chunk = draw();
     }

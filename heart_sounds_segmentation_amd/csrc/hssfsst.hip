@@ -523,15 +523,21 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
             static const int zgrid_env = std::getenv("HSSFSST_ZGRID") ? std::atoi(std::getenv("HSSFSST_ZGRID")) : 0;
             static const bool split_stats = std::getenv("HSSFSST_SPLIT_STATS") != nullptr;   // A/B: separate statistics launch
             int64_t zgrid = zgrid_env > 0 ? zgrid_env : (piped ? 512 : 4096);
-            if (zgrid > cb) zgrid = cb;
-            // a block per signal: it reduces the signal's partials itself (no separate statistics launch) unless
-            // one block sweeps many signals, where a tiny kernel doing all reductions at once is cheaper
-            const bool fused = !split_stats && zgrid == cb;
+            // small batches: several blocks per signal, else one block per signal would leave most CUs idle
+            int slices = 1;
+            if (zgrid_env <= 0 && !piped && cb < 1024) {
+                slices = static_cast<int>(1024 / cb);
+                if (slices > 32) slices = 32;
+            }
+            if (zgrid > cb * slices) zgrid = cb * slices;
+            // big batches, a block per signal: it reduces the signal's partials itself (no separate statistics
+            // launch, 4-7 us per step); otherwise a tiny kernel does all reductions at once
+            const bool fused = !split_stats && slices == 1 && zgrid == cb && cb >= 512;
             if (!fused)
                 hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, zs,
                                    cp.partials, cstats, nblk, ncols, p->K);
             hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, zs,
-                               cout, cstats, fused ? cp.partials : nullptr, nblk, ncols, p->K, static_cast<int>(cb));
+                               cout, cstats, fused ? cp.partials : nullptr, nblk, ncols, p->K, static_cast<int>(cb), slices);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -609,7 +615,7 @@ int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int 
                        state, stats, static_cast<int>(batch));
     const int64_t zgrid = batch < 4096 ? batch : 4096;
     hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, st,
-                       feats, stats, static_cast<const double*>(nullptr), 0, n, p->K, static_cast<int>(batch));
+                       feats, stats, static_cast<const double*>(nullptr), 0, n, p->K, static_cast<int>(batch), 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
