@@ -16,6 +16,7 @@
 
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
+#include "fourier_resample.hpp"
 #include <cstdlib>
 
 namespace {
@@ -569,6 +570,18 @@ int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, in
     hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), feats, state, n, p->K);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hssfsst_resample(const double* x, int64_t n, int64_t num, double* y)
+{
+    if (!x || !y || n < 1 || num < 1) return fail(HSSFSST_EINVAL, "hssfsst_resample: bad argument (n=%lld num=%lld)",
+                                                   static_cast<long long>(n), static_cast<long long>(num));
+    try {
+        if (!hssfsst::fourier_resample(x, n, num, y)) return fail(HSSFSST_EINVAL, "hssfsst_resample: bad argument");
+    } catch (const std::bad_alloc&) {
+        return fail(HSSFSST_ENOMEM, "hssfsst_resample: out of host memory");
+    }
     return 0;
 }
 

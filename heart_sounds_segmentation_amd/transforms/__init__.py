@@ -1,4 +1,5 @@
-"""Mirror of ``hss.transforms`` (/root/reference/hss/transforms/__init__.py:1-8) for the hot path."""
+"""Mirror of ``hss.transforms`` (/root/reference/hss/transforms/__init__.py:1-8)."""
+from .resample import Resample
 from .synchrosqueeze import FSST
 
-__all__ = ["FSST"]
+__all__ = ["Resample", "FSST"]

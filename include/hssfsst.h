@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 100
+#define HSSFSST_VERSION 101
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -118,6 +118,11 @@ int hssfsst_normalize_running(hssfsst_plan* plan, float* feats, int64_t batch, i
  * integral label columns).  Fills at most `cap` rows; returns the number of data rows in the file
  * (call once with cap = 0 to size the buffers) or a negative status on a malformed line. */
 int64_t hssfsst_parse_signal_csv(const char* text, int64_t len, float* signals, int64_t* labels, int64_t cap);
+
+/* Host helper, no device needed: replaces Resample.__call__ (hss/transforms/resample.py:13-21), i.e.
+ * scipy.signal.resample(x, num) for a real 1-D sequence (Fourier method, window=None): y[0..num) from x[0..n).
+ * Used by the dataset for the label path (hss/datasets/heart_sounds.py:202-207: round(Resample(y)) - 1). */
+int hssfsst_resample(const double* x, int64_t n, int64_t num, double* y);
 
 int hssfsst_device_count(void);
 int hssfsst_version(void);

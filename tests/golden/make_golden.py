@@ -10,6 +10,9 @@ The reference's Python files are imported here -- never copied -- to produce inp
   the core itself stays unpinned (see oracle/fsst_oracle.c header).
 * ``hss/utils/preprocess.py`` (frame_signal) -> frame start indices and shapes.
 * ``hss/moments/__init__.py`` (update_mean / update_variance) -> scalar sequences.
+* ``hss/transforms/resample.py`` (class Resample, scipy.signal.resample underneath) -> resampled signals and the
+  label rule of ``hss/datasets/heart_sounds.py:205-206``; the input of the reference's own test
+  (``test/test_transforms.py:12-14``) is one of the cases.  This pins oracle/resample_numpy.py to the real reference.
 
 The committed fixtures are data only (inputs + expected outputs).
 """
@@ -119,6 +122,33 @@ def main():
     np.savez_compressed(os.path.join(HERE, "moments.npz"), xs=xs, means=np.asarray(means),
                         m2s=np.asarray(m2s))
     print("moments final", means[-1], m2s[-1] / 63, xs.mean(), xs.var(ddof=1))
+
+    # Resample (hss/transforms/resample.py:5-21) and the label rule of heart_sounds.py:205-206
+    ref_rs = _load("ref_resample", os.path.join(REF, "hss/transforms/resample.py"))
+    rs = {}
+    def add_rs(tag, x, num, dtype=torch.float32):
+        y = ref_rs.Resample(num)(x, dtype) if dtype is not torch.float32 else ref_rs.Resample(num)(x)
+        rs[f"{tag}__x"] = x.numpy(); rs[f"{tag}__num"] = np.int64(num); rs[f"{tag}__y"] = y.numpy()
+        print("resample", tag, tuple(x.shape), x.dtype, "->", tuple(y.shape), y.dtype)
+    add_rs("ref_test_input_100", torch.tensor([1, 2, 3, 5]), 100)          # test/test_transforms.py:12-14, num = 100
+    add_rs("ref_test_3_to_50", torch.tensor([1, 2, 3]), 50)                # test/test_transforms.py:33-42
+    add_rs("ref_test_5_to_50", torch.tensor([1, 2, 3, 4, 5]), 50)
+    add_rs("down_even_even", torch.from_numpy(rng.standard_normal(64)), 20, torch.float64)
+    add_rs("down_even_odd", torch.from_numpy(rng.standard_normal(64)), 21, torch.float64)
+    add_rs("down_odd_even", torch.from_numpy(rng.standard_normal(75)), 30, torch.float64)
+    add_rs("up_even_odd", torch.from_numpy(rng.standard_normal(40)), 97, torch.float64)
+    add_rs("up_odd_even", torch.from_numpy(rng.standard_normal(41)), 128, torch.float64)
+    add_rs("same_len", torch.from_numpy(rng.standard_normal(50)), 50, torch.float64)
+    add_rs("to_one", torch.from_numpy(rng.standard_normal(9)), 1, torch.float64)
+    add_rs("from_one", torch.from_numpy(rng.standard_normal(1)), 7, torch.float64)
+    add_rs("pcg_f32_1000_to_500", torch.from_numpy(synth.pcg_windows(1, 1000, seed=3)[0]), 500)
+    # label path: labels 1..4 in runs, as in the corpus; y_new = round(Resample(y)) - 1
+    lab = torch.from_numpy(np.repeat(np.tile(np.array([1, 2, 3, 4], dtype=np.int64), 9), 71)[:2500])
+    t = ref_rs.Resample(1250)
+    rs["labels__y"] = lab.numpy(); rs["labels__num"] = np.int64(1250)
+    rs["labels__out"] = (torch.round(t(lab)).type(torch.int64) - 1).numpy()
+    rs["labels__raw"] = t(lab, torch.float64).numpy()
+    np.savez_compressed(os.path.join(HERE, "resample.npz"), **rs)
 
     # consumer of the features (hss/model/segmenter.py:5-87) at a reduced hidden size: weights, the
     # non-persistent random h0/c0, an input and the reference module's output (eval mode)

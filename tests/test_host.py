@@ -24,7 +24,7 @@ def test_constructor_signature_matches_reference():
     tf = FSST(1000, KAISER, truncate_freq=(25, 200), stack=True)
     assert tf.fs == 1000 and tf.window is KAISER and tf.abs is False and tf.stack is True
     assert tf.truncate_freq == (25, 200) and tf.dtype is torch.float32
-    assert transforms.__all__ == ["FSST"] and callable(tf)
+    assert transforms.__all__ == ["Resample", "FSST"] and callable(tf)      # hss/transforms/__init__.py:5-8
 
 
 def test_band_geometry_on_host(built_lib):
