@@ -72,8 +72,9 @@ struct Core128Params {
 };
 
 // Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
-// quarter or so, then 2-group chunks at the very end (each chunk costs a ticket, a tile staging and a statistics
-// reduction, so the small ones are kept to the tail).
+// quarter or so, then 2-group chunks at the very end (each chunk costs a counter draw, a tile staging and a
+// statistics reduction, so the small ones are kept to the tail).  Measured (tools/tail_sweep.sh): (16, 6) 0.1691 ms,
+// (24, 2) 0.1683, (32, 6) 0.1701, (8, 4) 0.1738, 8-group chunks only 0.1749.
 inline Core128Regions core128_regions(int ngroups)
 {
     Core128Regions r{};
@@ -267,10 +268,11 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid = batch * ceil(nblk / 4) blocks of 4 waves; each WAVE owns a tile of FPW consecutive frames of
-// one signal and walks it in groups of 16 frames, independently of its sibling waves (no block
-// barrier after the prologue).
-// LDS: atab[16 taps][64 lanes][2] (shared, 8 KB) | per wave: xs[FPW+127] | own | disp.
+// grid = persistent blocks of WPB waves (see "Work distribution" above); each WAVE draws chunks of one signal from
+// the block's LDS counter, stages FPW + 127 samples per FPW frames and walks them in groups of 16 frames,
+// independently of its sibling waves (no block barrier after the prologue).
+// LDS: atab[16 taps][64 lanes][2] (shared, 8 KB) | control words + FAST store-offset table | per wave: xs[FPW+127] |
+//      own plane | displaced plane | flag.
 // ------------------------------------------------------------------------------------------------
 // FAST: the time-major [re | im] epilogue with 16-byte stores (mode STACK / STACK_UNNORM, K even, K <= 24 -- the
 // canonical configuration); otherwise the general epilogue (raw / abs / any K).  The host picks.
