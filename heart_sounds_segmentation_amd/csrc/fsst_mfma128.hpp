@@ -78,8 +78,14 @@ struct Core128Params {
 inline Core128Regions core128_regions(int ngroups)
 {
     Core128Regions r{};
+#ifdef HSS_TAIL_ENV                                      // development only (tools/tail_sweep.sh)
+    static const int env2 = std::getenv("HSSFSST_TAIL2") ? std::atoi(std::getenv("HSSFSST_TAIL2")) : 6;
+    static const int env4 = std::getenv("HSSFSST_TAIL4") ? std::atoi(std::getenv("HSSFSST_TAIL4")) : 16;
+    const int tail2 = ngroups >= 32 ? env2 : 0, tail4 = ngroups >= 32 ? env4 : 0;
+#else
     const int tail2 = ngroups >= 32 ? 6 : 0;             // groups wanted as 2-group chunks
     const int tail4 = ngroups >= 32 ? 16 : 0;            // groups wanted as 4-group chunks
+#endif
     int big = ngroups - tail2 - tail4;
     big -= big % 8;                                      // whole 8-group chunks only
     if (big < 0) big = 0;
