@@ -110,6 +110,21 @@ def test_ragged_lengths(oracle_mod, n):
         _run_and_check(oracle_mod, X, 1000, KAISER, BAND, stack=True, what=f"n={n}/stack")
 
 
+@pytest.mark.parametrize("n,batch", [(496, 3), (511, 2), (512, 2), (513, 1), (528, 5), (1999, 2), (2016, 1), (600, 300)])
+def test_chunk_pattern_edges(oracle_mod, n, batch):
+    """Lengths around the region boundaries of the persistent core's chunk list (31 / 32 / 33 groups of 16 frames,
+    a last chunk of one group, ...) and a batch with more chunks than resident waves; stack mode, so the per-chunk
+    statistics partials are covered too.  Also: the result does not depend on what else is in the batch."""
+    X = synth.noise_windows(batch, n, seed=7 * n + batch)
+    got, ref, _ = _run_and_check(oracle_mod, X[: min(batch, 4)], 1000, KAISER, BAND, stack=True, what=f"edges n={n}")
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    full = tf.batch(torch.from_numpy(X).cuda())
+    assert torch.equal(full[: min(batch, 4)].cpu(), torch.from_numpy(got))
+    if batch > 1:
+        alone = tf.batch(torch.from_numpy(X[batch - 1:]).cuda())
+        assert torch.equal(alone[0], full[batch - 1])
+
+
 def test_whole_recording(oracle_mod):
     # lazy dataset path: the transform gets a whole recording (heart_sounds.py:175-182)
     x = synth.recording(35500)
