@@ -191,7 +191,7 @@ __host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
 __host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
 __host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
-constexpr int kCtlFloats = 4 + 6 * 64;       // block control words in LDS: chunk counter, FAST store-offset table
+constexpr int kCtlFloats = 4;                // block control words in LDS (chunk counter)
 
 // FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
 // float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
@@ -314,11 +314,6 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane == 0) *flag = 0;
     if (threadIdx.x == 0) *next_q = 0;
-    if constexpr (FAST) {
-        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
-        int* dstp = reinterpret_cast<int*>(smem + 2 * 16 * 64 + 4);
-        for (int i = threadIdx.x; i < 6 * 64; i += 64 * WPB) dstp[i] = ptab[i];
-    }
     __syncthreads();
 
     // chunk bookkeeping (wave-uniform)
@@ -344,9 +339,15 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // byte offsets in the own plane of the two pairs that make up this lane's i-th float4
-    // (the host-made offset table, core128_store_offsets, sits in LDS and is re-read per group: 6 ds_read instead
-    //  of 6 VGPRs pinned through the whole kernel, which is what pushed the register allocation into scratch)
-    const int* ptab_lds = reinterpret_cast<const int*>(smem + 2 * 16 * 64 + 4) + lane;
+    // this lane's six LDS byte offsets of the store pass (host-made table, core128_store_offsets), two 16-bit
+    // offsets per register: three VGPRs for the whole kernel (six pushed the register allocation into scratch)
+    unsigned ppk[3] = {0u, 0u, 0u};
+    if constexpr (FAST) {
+        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            ppk[i] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
+    }
     while (chunk < nchunks) {
     // decode: region, signal, first group, number of groups, statistics slot
     const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
@@ -466,10 +467,6 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         const int nvalid = min(16, cend - tg);
         const int koff = klo - 8 * s0;
         if constexpr (FAST) {
-            // this lane's store offsets for the group (read here, used after the statistics: latency hidden)
-            int pofs[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) pofs[i] = ptab_lds[i * 64];
             // lane (g, j): frame j, kept rows k = g + 4 u (u < 6 covers K <= 24) as packed (re, im) cells
             f2* src = own_base + j * OLD + koff + g;
             if (wdirty) {                                    // (rare) fold the displaced plane into the own plane
@@ -514,7 +511,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int p0 = pofs[i], p1 = pofs[3 + i];
+                const int p0 = static_cast<int>(ppk[i] & 0xffffu), p1 = static_cast<int>(ppk[i] >> 16);
                 o[i].x = *reinterpret_cast<const float*>(ob + p0);
                 o[i].y = *reinterpret_cast<const float*>(ob + p0 + 8);
                 o[i].z = *reinterpret_cast<const float*>(ob + p1);
