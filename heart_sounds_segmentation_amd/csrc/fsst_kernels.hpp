@@ -48,6 +48,7 @@ struct CoreParams {
     int nblk;             // tiles per signal
     int col0;             // first output column (frame centre) of every signal
     int ncols;            // number of output columns (== n for a whole-signal transform)
+    int oneplane;         // 1: own and displaced values share one LDS plane (wide bands)
 };
 
 // Window tables are read-only for the whole launch and indexed wave-uniformly: the constant
@@ -135,6 +136,7 @@ struct Scatter {
     float* disp;
     int klo;
     int K;
+    bool oneplane;        // own == disp (wide bands that do not fit two planes in LDS): own-row values are accumulated
     __device__ __forceinline__ void add(int row, float re, float im) const
     {
         const int idx = row - klo;
@@ -164,8 +166,13 @@ __device__ __forceinline__ void scatter_source(const Scatter<LD>& sc, float kp, 
     const float re = sgn * p, im = sgn * q;
     const int slot = kpi - sc.klo;                        // wave-uniform
     if (static_cast<unsigned>(slot) < static_cast<unsigned>(sc.K)) {
-        sc.own[slot * LD] = moved ? 0.0f : re;
-        sc.own[(sc.K + slot) * LD] = moved ? 0.0f : im;
+        if (sc.oneplane) {                                // wave-uniform
+            sc.own[slot * LD] += moved ? 0.0f : re;
+            sc.own[(sc.K + slot) * LD] += moved ? 0.0f : im;
+        } else {
+            sc.own[slot * LD] = moved ? 0.0f : re;
+            sc.own[(sc.K + slot) * LD] = moved ? 0.0f : im;
+        }
     }
     if (moved) {
         float shift = num * __builtin_amdgcn_rcpf(den);
@@ -259,6 +266,8 @@ __device__ __forceinline__ double wave_sum(double v)
 // ------------------------------------------------------------------------------------------------
 // Core kernel: one block = one TILE-sample stretch of one signal; one lane = one hop-1 frame.
 // LDS: xs[TILE + nwin - 1 (+pad)] | own[2K][TILE + 1] | disp[2K][TILE + 1]; red[] aliases xs.
+// p.oneplane != 0: own and disp are the same plane (half the LDS; every own-row value then costs a read-modify-write
+// instead of a store) -- used by the host when two planes of the kept band do not fit 160 KB (nwin = 512, wide bands).
 // ------------------------------------------------------------------------------------------------
 template <int R, int TILE>
 __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
@@ -284,11 +293,12 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
         const int g = t0 + i - NWIN / 2;
         xs[i] = (g >= 0 && g < n) ? xsig[g] : 0.0f;
     }
-    float* disp = own + 2 * K * LD;
+    const bool oneplane = p.oneplane != 0;
+    float* disp = oneplane ? own : own + 2 * K * LD;
     for (int c = 0; c < 2 * K; ++c) disp[c * LD + tid] = 0.0f;
     __syncthreads();
 
-    const Scatter<LD> sc{own + tid, disp + tid, p.klo, K};
+    const Scatter<LD> sc{own + tid, disp + tid, p.klo, K, oneplane};
     const float* myx = xs + tid;
     ctab_ptr tab = (ctab_ptr)p.ctab;
     packed_class<R, false, LD>(tab, myx, sc);
@@ -303,7 +313,9 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     }
     __syncthreads();
     // fold the displaced plane into the own plane (each lane its own column: no hazard)
-    for (int c = 0; c < 2 * K; ++c) own[c * LD + tid] += disp[c * LD + tid];
+    if (!oneplane) {
+        for (int c = 0; c < 2 * K; ++c) own[c * LD + tid] += disp[c * LD + tid];
+    }
     __syncthreads();
     float* acc = own;
 

@@ -140,11 +140,16 @@ namespace {
 int out_floats_per_sample(const hssfsst_plan* p) { return p->mode == HSSFSST_MODE_ABS ? p->K : 2 * p->K; }
 
 template <int R>
-int launch_core(const hssfsst_plan* pl, const hssfsst::CoreParams& cp, long long nblocks, hipStream_t st)
+int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblocks, hipStream_t st)
 {
     constexpr int NWIN = 32 * R;
     constexpr int XS = ((kTile + NWIN - 1 + 3) / 4) * 4;
-    const size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(4 * pl->K) * (kTile + 1)) * sizeof(float);
+    size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(4 * pl->K) * (kTile + 1)) * sizeof(float);
+    cp.oneplane = 0;
+    if (lds > 160 * 1024) {                              // wide band: own and displaced values share one plane
+        lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * pl->K) * (kTile + 1)) * sizeof(float);
+        cp.oneplane = 1;
+    }
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     auto kern = hssfsst::fsst_core_kernel<R, kTile>;
     if (lds > 32 * 1024)

@@ -125,6 +125,16 @@ def test_chunk_pattern_edges(oracle_mod, n, batch):
         assert torch.equal(alone[0], full[batch - 1])
 
 
+@pytest.mark.parametrize("mode", ["raw", "abs", "stack"])
+def test_nwin512_full_band_single_plane(oracle_mod, mode):
+    """257 kept rows at nwin = 512 do not fit two LDS planes: the generic kernel then shares one plane between
+    own-row and displaced values (fsst_core_kernel, oneplane)."""
+    from scipy.signal import get_window
+    w = get_window(("kaiser", 0.5), 512, fftbins=False)
+    X = synth.pcg_windows(2, 700, fs=4000, seed=12)
+    _run_and_check(oracle_mod, X, 4000, w, None, abs_=(mode == "abs"), stack=(mode == "stack"), what=f"nwin512 full {mode}")
+
+
 def test_whole_recording(oracle_mod):
     # lazy dataset path: the transform gets a whole recording (heart_sounds.py:175-182)
     x = synth.recording(35500)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: random (batch, n, band, mode, window, nwin, input scale) against the fp64
+oracle with the gate of tests/parity.py.  usage: fuzz_parity.py [cases=150] [seed=1]
+Outcomes are classified: errors (exceptions) and gate failures with the near-rectangular Kaiser(0.5) window are real
+failures (exit 1); with heavy-reassignment windows (Hann, Hamming, Kaiser beta 6) two things are expected and only
+counted: more rounding-fragile columns than the budget (at nwin = 512 a column has 257 sources, each within 1e-3 of a
+rounding tie with probability ~1e-3) and isolated fp32-vs-fp64 rounding flips in columns the oracle calls robust
+(profiles/r01_flip_census.txt)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from heart_sounds_segmentation_amd import FSST, synth
+from tests import parity
+from scipy.signal import get_window
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fails = 0; t_start = time.time(); worst = 0.0; heavy_budget = 0; heavy_flip = 0; ran = 0
+for case in range(ncases):
+    nwin = int(rng.choice([128, 128, 128, 64, 256, 32, 512]))
+    wkind = rng.choice(["kaiser0.5", "kaiser6", "hann", "hamming"])
+    w = {"kaiser0.5": get_window(("kaiser", 0.5), nwin, fftbins=False), "kaiser6": get_window(("kaiser", 6.0), nwin, fftbins=False),
+         "hann": get_window("hann", nwin, fftbins=False), "hamming": get_window("hamming", nwin, fftbins=False)}[wkind]
+    fs = float(rng.choice([1000, 2000, 4000]))
+    n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 700), rng.integers(700, 2300)]))
+    batch = int(rng.choice([1, 2, 3, 7, rng.integers(8, 40)]))
+    mode = str(rng.choice(["stack", "stack", "abs", "raw"]))
+    if rng.random() < 0.3:
+        band = None
+    else:
+        lo = float(rng.uniform(0, fs / 4)); hi = float(rng.uniform(lo, fs / 2))
+        band = (lo, hi)
+    kind = rng.choice(["noise", "pcg"])
+    X = synth.noise_windows(batch, n, seed=int(rng.integers(1 << 30))) if kind == "noise" else synth.pcg_windows(batch, n, fs=fs, seed=int(rng.integers(1 << 30)))
+    scale = float(10.0 ** rng.integers(-3, 4)); X = (X * scale).astype(np.float32)
+    desc = f"case {case}: nwin={nwin} {wkind} fs={fs:g} n={n} batch={batch} mode={mode} band={band} {kind} x{scale:g}"
+    try:
+        tf = FSST(fs, w, truncate_freq=band, stack=(mode == "stack"), abs=(mode == "abs"))
+        lo_k, K = tf.band() if hasattr(tf, "band") else (0, 1)
+        if K == 0 or (mode == "stack" and n * K < 2):
+            continue
+        got = tf.batch(torch.from_numpy(X).cuda()).cpu().numpy()
+        ref, hd = oracle.features(X, fs, w, band, mode, nthreads=os.cpu_count(), return_halfdist=True)
+        heavy = wkind in ("hann", "hamming", "kaiser6")
+        ran += 1
+        for b in range(batch):
+            if mode == "stack" and not np.isfinite(ref[b]).all():
+                continue                                  # degenerate statistics (constant block): reference gives NaN/inf too
+            r = parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=desc, frag_budget=0.35 if heavy else 0.05)
+            worst = max(worst, r["rel"])
+    except AssertionError as e:
+        msg = str(e)
+        if heavy and "fragile columns exceed the budget" in msg:
+            heavy_budget += 1
+        elif heavy and ("max err" in msg or "rel L2" in msg):
+            heavy_flip += 1; print("flip (heavy window)", desc, "\n    ", msg[:200], flush=True)
+        else:
+            fails += 1; print("FAIL", desc, "\n    ", msg[:300], flush=True)
+    except Exception as e:                                # noqa: BLE001
+        fails += 1; print("ERROR", desc, "\n    ", type(e).__name__, str(e)[:300], flush=True)
+print(f"{ncases} cases drawn, {ran} run: {fails} failures; heavy-window cases over the fragile-column budget {heavy_budget}, "
+      f"with a rounding flip in a robust column {heavy_flip}; worst robust rel err of the passing signals {worst:.2e}; "
+      f"{time.time() - t_start:.0f} s")
+sys.exit(1 if fails else 0)
