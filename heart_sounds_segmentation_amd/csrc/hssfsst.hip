@@ -146,7 +146,11 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     constexpr int XS = ((kTile + NWIN - 1 + 3) / 4) * 4;
     size_t lds = (static_cast<size_t>(XS) + static_cast<size_t>(4 * pl->K) * (kTile + 1)) * sizeof(float);
     cp.oneplane = 0;
-    if (lds > 160 * 1024) {                              // wide band: own and displaced values share one plane
+    // wide band: own and displaced values share one plane.  Needed above 160 KiB (nwin 512, > ~150 kept rows) and
+    // already worth it above 40 KiB, where LDS is what limits the resident waves (measured, 1024 x 2000, band
+    // [25,200] Hz: nwin 256 core 2.25 -> 1.44 ms, nwin 512 18.9 -> 9.4 ms; HSSFSST_ONEPLANE_KB overrides)
+    static const int one_thr = std::getenv("HSSFSST_ONEPLANE_KB") ? std::atoi(std::getenv("HSSFSST_ONEPLANE_KB")) : 40;
+    if (lds > static_cast<size_t>(one_thr) * 1024) {
         lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * pl->K) * (kTile + 1)) * sizeof(float);
         cp.oneplane = 1;
     }
