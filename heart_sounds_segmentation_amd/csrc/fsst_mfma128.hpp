@@ -411,33 +411,8 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
             });
         });
 #if !defined(HSS_ABLATE) || HSS_ABLATE < 4
-#ifdef HSS_ASM_STAGE1
-        // First (twiddle-free) FFT stage in packed math, straight on the MFMA results.  The compiler emits these 32
-        // butterfly outputs as 64 scalar adds (it extracts the accumulator lanes one by one); a VALU instruction
-        // that reads a matrix-pipe result costs about twice a normal one (profiles/r01_mfma_rate_ubench.txt, V13 vs
-        // V7), so 32 packed instructions are worth forcing.  Inline asm is invisible to the compiler's MFMA->VALU
-        // hazard padding, hence the fixed order: nothing crosses the scheduling barrier, and the butterflies of
-        // taps 0-3 / 8-11 (whose MFMAs are at least 8 matrix instructions old) go first, so the first read of a
-        // result of the last MFMA group comes 16 VALU instructions after it was issued (required: 11 wait states).
-        __builtin_amdgcn_sched_barrier(0);
-        auto bfly0 = [&](f2& e, f2& o) {
-            f2 a, b;
-            asm volatile("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"
-                         : "=&v"(a), "=&v"(b) : "v"(e), "v"(o));
-            e = a; o = b;
-        };
-        static_for<8>([&](auto NN) {
-            constexpr int e = bitrev4(decltype(NN)::value);   // taps nn and nn + 8 sit in slots e and e + 1
-            bfly0(za[e], za[e + 1]);
-            bfly0(zb[e], zb[e + 1]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        fft16<1>(za);
-        fft16<1>(zb);
-#else
         fft16(za);
         fft16(zb);
-#endif
 #endif
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 3
         {   // development only: keep the spectra alive without the source stage
