@@ -187,19 +187,25 @@ __device__ __forceinline__ void fft16(f2 (&z)[16])
 //   disp [16 frames][LDF(K)]  kept rows only, zero-initialised: corrections from displaced sources.
 __host__ __device__ constexpr int odd_up(int v) { return (v & 1) ? v : v + 1; }      // odd => b64 conflict-free
 __host__ __device__ constexpr int plane_ldf(int K) { return odd_up(K); }
-__host__ __device__ constexpr int own_s0(int klo) { return klo >> 3; }
-__host__ __device__ constexpr int own_s1(int klo, int K) { return (klo + K - 1) >> 3; }          // inclusive stripe
-__host__ __device__ constexpr int own_ld(int klo, int K) { return odd_up(8 * (own_s1(klo, K) - own_s0(klo) + 1) + 1); }
+// rq = first-stage radix = rows per stripe (8 for nwin = 128, 16 for nwin = 256): source k' = rq * s + r sits in stripe s
+__host__ __device__ constexpr int own_s0(int klo, int rq = 8) { return klo / rq; }
+__host__ __device__ constexpr int own_s1(int klo, int K, int rq = 8) { return (klo + K - 1) / rq; }   // inclusive stripe
+__host__ __device__ constexpr int own_ld(int klo, int K, int rq = 8)
+{
+    return odd_up(rq * (own_s1(klo, K, rq) - own_s0(klo, rq) + 1) + 1);
+}
+// MFMA A-operand constants: [pass][16 taps][k-step][64 lanes] floats, rq / 8 passes of rq / 4 k-steps
+__host__ __device__ constexpr int core128_atab_floats(int rq = 8) { return (rq / 8) * 16 * (rq / 4) * 64; }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
 constexpr int kCtlFloats = 4;                // block control words in LDS (chunk counter)
 
 // FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
 // float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
 // tab[i][lane] = first pair, tab[3 + i][lane] = second pair; a pair's second element is 8 bytes further.
-inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */)
+inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq = 8)
 {
     const int Q = (K >> 1) > 0 ? (K >> 1) : 1;
-    const int old = own_ld(klo, K), koff0 = klo - 8 * own_s0(klo);
+    const int old = own_ld(klo, K, rq), koff0 = klo - rq * own_s0(klo, rq);
     for (int i = 0; i < 3; ++i)
         for (int lane = 0; lane < 64; ++lane) {
             const int f = lane + 64 * i;
@@ -209,9 +215,9 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */)
             tab[(3 + i) * 64 + lane] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
         }
 }
-__host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K)
+__host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8)
 {
-    return ((fpw + 127 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K) + plane_ldf(K)) + 4;   // + dirty flag
+    return ((fpw + 16 * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4;   // + dirty flag
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -224,6 +230,7 @@ __device__ __forceinline__ void wave_sync()
 // Exact (rare) path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32.  `row_disp`
 // points at this lane's frame row in the displaced plane; the own plane already holds V in the
 // source's own column (unconditional store), so V is first taken out again there.
+template <int NWIN>
 __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int klo, int K, int kpi,
                                                  float num, float den, f2 V)
 {
@@ -238,13 +245,13 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
     const float a = kf + shift;
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    const int row = static_cast<int>(r) & 127;
+    const int row = static_cast<int>(r) & (NWIN - 1);
     if (row == kpi) return;                             // rounds back into its own row after all
     const int own = kpi - klo, idx = row - klo;
     if (static_cast<unsigned>(own) < static_cast<unsigned>(K)) add(own, -V.x, -V.y);
     if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) add(idx, V.x, V.y);
-    if (kpi != 0) {                                     // negative-frequency twin (k' = 64 never moves)
-        const int idm = ((128 - row) & 127) - klo;      // row -> 128 - row, value conj
+    if (kpi != 0) {                                     // negative-frequency twin (k' = nwin/2 never moves)
+        const int idm = ((NWIN - row) & (NWIN - 1)) - klo;      // row -> nwin - row, value conj
         if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) add(idm, V.x, -V.y);
     }
 }
@@ -258,7 +265,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // the wave run the exact rounding path for it.  (Folding the 1/2 into the constants by doubling dw' saves
 // one more multiply per source, 1 % of the kernel, but doubles the cancellation error of V for far-moving
 // cells: measured 5 instead of 3 rounding flips per 918 k robust Hann columns, so it is not done.)
-template <int S>
+template <int S, int RQ>
 __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot, bool store, f2* row_disp,
                                                int* flag, int klo, int K, int r)
 {
@@ -270,7 +277,7 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
         q[0] = t1.x; q[1] = t2.x;
     }
     if (fabsf(dn.y) >= 0.5f * dn.x)                     // skipped when no lane moved (execz)
-        displaced_source(row_disp, flag, klo, K, r + 8 * S, dn.y, dn.x, f2{t1.x, t2.x});
+        displaced_source<16 * RQ>(row_disp, flag, klo, K, r + RQ * S, dn.y, dn.x, f2{t1.x, t2.x});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,15 +290,21 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
 // FAST: the time-major [re | im] epilogue with 16-byte stores (mode STACK / STACK_UNNORM, K even, K <= 24 -- the
 // canonical configuration); otherwise the general epilogue (raw / abs / any K).  The host picks.
 // WPB: waves per block -- 16 (a whole CU) whenever 16 wave regions fit the 160 KB of LDS, else 8 / 4 / 2 / 1.
-template <int FPW, bool FAST, int WPB>
-__global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core128Params p)
+// RQ: radix of the first (matrix-pipe) stage, nwin = 16 RQ.  RQ = 8 is the canonical nwin = 128; RQ = 16 (nwin = 256)
+// runs the same 8-class structure twice per group of frames ("passes": classes {0,8,1,15,2,14,3,13}, then
+// {4,12,...,7,9}), each tap as a chain of RQ / 4 MFMA k-steps.
+template <int RQ, int FPW, bool FAST, int WPB>
+__global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_core128_kernel(Core128Params p)
 {
-    constexpr int XS = ((FPW + 127 + 3) / 4) * 4;
+    constexpr int NWIN = 16 * RQ, NPASS = RQ / 8, KST = RQ / 4;
+    constexpr int ATAB = core128_atab_floats(RQ);
+    constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
+    using avec = float __attribute__((ext_vector_type(KST)));          // one tap's A operand, all k-steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.K, klo = p.klo, n = p.n;
     const int LDF = plane_ldf(K);
-    const int OLD = own_ld(klo, K);
-    const int s0 = own_s0(klo), s1 = own_s1(klo, K);
+    const int OLD = own_ld(klo, K, RQ);
+    const int s0 = own_s0(klo, RQ), s1 = own_s1(klo, K, RQ);
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -299,17 +312,20 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
 #ifdef HSS_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
-    f2* atab = reinterpret_cast<f2*>(smem);                                  // [16][64]
-    int* next_q = reinterpret_cast<int*>(smem + 2 * 16 * 64);               // block's chunk counter
-    float* wbase = smem + 2 * 16 * 64 + kCtlFloats + wv * wave_lds_floats(FPW, klo, K);
+    float* atab = smem;                                                      // [pass][16 taps][64 lanes][KST]
+    int* next_q = reinterpret_cast<int*>(smem + ATAB);                       // block's chunk counter
+    float* wbase = smem + ATAB + kCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
 
-    // shared MFMA A operand: atab[tap][lane] = (k-half 0, k-half 1)
-    for (int i = threadIdx.x; i < 16 * 64; i += 64 * WPB)
-        atab[i] = f2{p.atab[(2 * (i >> 6)) * 64 + (i & 63)], p.atab[(2 * (i >> 6) + 1) * 64 + (i & 63)]};
+    // shared MFMA A operand, regrouped so that a lane reads all k-steps of a tap with one LDS instruction:
+    // global [pass * 16 + tap][k-step][lane]  ->  LDS [pass * 16 + tap][lane][k-step]
+    for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) {
+        const int ks = i % KST, l = (i / KST) & 63, pt = i / (KST * 64);
+        atab[i] = p.atab[(pt * KST + ks) * 64 + l];
+    }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane == 0) *flag = 0;
@@ -329,12 +345,8 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         return c < nchunks ? static_cast<int>(c) : nchunks;
     };
     int chunk = draw();
-    const bool isg0 = (g == 0);
-    const int rA = g, rB = isg0 ? 4 : 8 - g;
-    f2* ownA = own_base + j * OLD + rA - 8 * s0;         // column of k' = 8 s + rA at + 8 s
-    f2* ownB = own_base + j * OLD + rB - 8 * s0;
     f2* row_disp = disp_base + j * LDF;
-    const f2* myA = atab + lane;
+    const float* myA = atab + lane * KST;
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     // offsets per register: three VGPRs for the whole kernel (six pushed the register allocation into scratch)
     unsigned ppk[3] = {0u, 0u, 0u};
     if constexpr (FAST) {
-        const int* ptab = reinterpret_cast<const int*>(p.atab + 2 * 16 * 64);
+        const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             ppk[i] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
@@ -360,8 +372,8 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
     const int slot = ((rg > 0) ? p.reg.npc[0] : 0) + ((rg > 1) ? p.reg.npc[1] : 0) + cidx;
     const float* xsig = p.x + b * static_cast<long long>(n);
     auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
-        for (int i = lane; i < FPW + 127; i += 64) {
-            const int gi = t0 + i - 64;
+        for (int i = lane; i < FPW + NWIN - 1; i += 64) {
+            const int gi = t0 + i - NWIN / 2;
             xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
         }
     };
@@ -384,28 +396,43 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + lane)));
         asm volatile("" : "+v"(xaddr));
         const lds_float* xb = (const lds_float*)static_cast<size_t>(xaddr);
+        // ---- NPASS passes over the same 16 frames: pass pz handles class pairs 4 pz + g (pair 0 = the two
+        //      self-conjugate classes {0, RQ/2}, pair m = {m, RQ - m})
+        static_for<NPASS>([&](auto PZ) {
+        constexpr int pz = decltype(PZ)::value;
         // keep the per-lane class ids opaque inside the loop: otherwise LICM hoists every
-        // "rA + 8 s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
-        int rAi = rA, rBi = rB;
-        asm volatile("" : "+v"(rAi), "+v"(rBi));
+        // "rA + RQ s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
+        int pair = 4 * pz + g;
+        asm volatile("" : "+v"(pair));
+        const bool isg0 = (pz == 0) && (pair == 0);          // lane holds the self-conjugate pair
+        const int rAi = pair, rBi = isg0 ? RQ / 2 : RQ - pair;
+        f2* ownA = own_base + j * OLD + rAi - RQ * s0;       // column of k' = RQ s + rA at + RQ s
+        f2* ownB = own_base + j * OLD + rBi - RQ * s0;
+        const float* myAp = myA + pz * 16 * 64 * KST;
 
-        // ---- folded window + radix-8 stage on the matrix pipe: 16 taps x 2 k-halves
+        // ---- folded window + radix-RQ stage on the matrix pipe: 16 taps x KST k-steps
         f2 za[16], zb[16];
-        // four taps at a time: the four first k-halves, then the four second k-halves (the dependent MFMA of a
-        // tap is issued three MFMAs after its first half; measured 1 % faster than tap by tap)
+        // four taps at a time, k-step by k-step (the dependent MFMA of a tap is issued three MFMAs after the
+        // previous k-step of the same tap; measured 1 % faster than tap by tap)
         static_for<4>([&](auto GG) {
             constexpr int g0 = decltype(GG)::value * 4;
             f4 acc[4];
-            f2 a2[4];
+            avec a2[4];
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                a2[i] = myA[(g0 + i) * 64];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i].x, xb[g0 + i], f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                a2[i] = *reinterpret_cast<const avec*>(myAp + (g0 + i) * 64 * KST);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][0], xb[g0 + i], f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
             });
-            __builtin_amdgcn_sched_barrier(0);
+            static_for<KST - 1>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value + 1;
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<4>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][ks], xb[g0 + i + 64 * ks], acc[i], 0, 0, 0);
+                });
+            });
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i].y, xb[g0 + i + 64], acc[i], 0, 0, 0);
                 za[bitrev4(g0 + i)] = f2{acc[i].x, acc[i].y};
                 zb[bitrev4(g0 + i)] = f2{acc[i].z, acc[i].w};
             });
@@ -424,23 +451,31 @@ __global__ __launch_bounds__(64 * WPB, HSS_MW128) void fsst_core128_kernel(Core1
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
         static_for<8>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
-            // partner of a[s]: class 0 -> a[(16-s)&15];  else b[15-s].  partner of b[s]: class 4 -> b[15-s]; else a[15-s]
+            // partner of a[s]: class 0 -> a[(16-s)&15];  else b[15-s].  partner of b[s]: class RQ/2 -> b[15-s]; else a[15-s]
             const f2 pa0 = za[(16 - s) & 15], pb = zb[15 - s], pa = za[15 - s];
-            const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
-            const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+            f2 PA, PB;
+            if constexpr (pz == 0) {
+                PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
+                PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+            } else {                                         // no self-conjugate class in the later passes
+                PA = pb; PB = pa;
+            }
             const bool st = (s >= s0) && (s <= s1);
-            process_source<s>(za[s], PA, tiny, ownA + 8 * s, st, row_disp, flag, klo, K, rAi);
-            process_source<s>(zb[s], PB, tiny, ownB + 8 * s, st, row_disp, flag, klo, K, rBi);
+            process_source<s, RQ>(za[s], PA, tiny, ownA + RQ * s, st, row_disp, flag, klo, K, rAi);
+            process_source<s, RQ>(zb[s], PB, tiny, ownB + RQ * s, st, row_disp, flag, klo, K, rBi);
         });
-        // k' = 64 (class 0, j = 8) is its own partner: V = 2 Re(Z[64]) is real, its shift is exactly 0
-        if (s1 == 8 && isg0) own_base[j * OLD + 64 - 8 * s0] = f2{2.0f * za[8].x, 0.0f};
+        // k' = nwin/2 (class 0, j = 8) is its own partner: V = 2 Re(Z[nwin/2]) is real, its shift is exactly 0
+        if constexpr (pz == 0) {
+            if (s1 == 8 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[8].x, 0.0f};
+        }
 #endif
+        });
         wave_sync();
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
         const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
         const int nvalid = min(16, cend - tg);
-        const int koff = klo - 8 * s0;
+        const int koff = klo - RQ * s0;
         if constexpr (FAST) {
             // lane (g, j): frame j, kept rows k = g + 4 u (u < 6 covers K <= 24) as packed (re, im) cells
             f2* src = own_base + j * OLD + koff + g;

@@ -121,7 +121,8 @@ struct hssfsst_plan {
     int nwin = 0, R = 0, nf = 0, klo = 0, K = 0, mode = 0;
     double fs = 0.0;
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
-    float* d_atab = nullptr;      // nwin == 128: MFMA A-operand constants [32][64]
+    float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
+    int rq = 0;                   // first-stage radix of the MFMA kernel (nwin / 16), 0 = generic kernel
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
@@ -164,12 +165,12 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     return 0;
 }
 
-template <bool FAST, int WPB>
+template <int RQ, bool FAST, int WPB>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
-    const size_t lds = (2 * 16 * 64 + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
-                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
-    auto kern = hssfsst::fsst_core128_kernel<kFpw128, FAST, WPB>;
+    const size_t lds = (hssfsst::core128_atab_floats(RQ) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
+                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ)) * sizeof(float);
+    auto kern = hssfsst::fsst_core128_kernel<RQ, kFpw128, FAST, WPB>;
     if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
         if (lds > 32 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -200,13 +201,22 @@ int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* parti
     const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
                       (pl->K & 1) == 0 && pl->K <= 24;
     // waves per block: as many wave regions as fit the 160 KiB of LDS beside the shared tables
-    const size_t fixed = (2 * 16 * 64 + hssfsst::kCtlFloats) * sizeof(float);
-    const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K)) * sizeof(float);
+    const int rq = pl->rq;
+    const size_t fixed = (hssfsst::core128_atab_floats(rq) + hssfsst::kCtlFloats) * sizeof(float);
+    const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq)) * sizeof(float);
     const size_t room = 160 * 1024;
-    if (fast) return launch_core128_wpb<true, 16>(pl, cp, nchunks, st);       // K <= 24: 16 regions always fit
-    if (fixed + 16 * per_wave <= room) return launch_core128_wpb<false, 16>(pl, cp, nchunks, st);
-    if (fixed + 8 * per_wave <= room) return launch_core128_wpb<false, 8>(pl, cp, nchunks, st);
-    if (fixed + 4 * per_wave <= room) return launch_core128_wpb<false, 4>(pl, cp, nchunks, st);
+    if (rq == 8) {
+        if (fast) return launch_core128_wpb<8, true, 16>(pl, cp, nchunks, st);       // K <= 24: 16 regions always fit
+        if (fixed + 16 * per_wave <= room) return launch_core128_wpb<8, false, 16>(pl, cp, nchunks, st);
+        if (fixed + 8 * per_wave <= room) return launch_core128_wpb<8, false, 8>(pl, cp, nchunks, st);
+        if (fixed + 4 * per_wave <= room) return launch_core128_wpb<8, false, 4>(pl, cp, nchunks, st);
+    } else {                                                                         // rq == 16, nwin = 256
+        // (8 waves per block at most: two per SIMD, up to 256 VGPRs, no scratch)
+        if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, true, 8>(pl, cp, nchunks, st);
+        if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, false, 8>(pl, cp, nchunks, st);
+        if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, false, 4>(pl, cp, nchunks, st);
+        if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, true, 4>(pl, cp, nchunks, st);
+    }
     return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B per wave exceeds the 160 KiB budget", per_wave);
 }
 
@@ -318,30 +328,42 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     e = hipMemcpy(p->d_ctab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(p->d_ctab); delete p; return fail(HSSFSST_EHIP, "plan_create: hipMemcpy: %s", hipGetErrorString(e)); }
     const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
-    if (nwin == 128 && !(force && force[0] == '1')) {
-        // A[i][k] of v_mfma_f32_16x16x4_f32 for tap n, k-half h: lane l holds row i = l & 15, k = l >> 4.
-        // Row i: lane group gg = i >> 2 owns classes ca = gg and cb = (gg ? 8 - gg : 4); sub = i & 3:
+    static const bool mfma256 = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);     // A/B: nwin 256 on the generic kernel
+    bool use_mfma = (nwin == 128 || (nwin == 256 && mfma256)) && !(force && force[0] == '1');
+    if (use_mfma) {                                      // four wave regions of this band must fit beside the A table
+        const int rq0 = nwin / 16;
+        const size_t need = (hssfsst::core128_atab_floats(rq0) + hssfsst::kCtlFloats +
+                             4 * static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, p->klo, p->K, rq0))) * sizeof(float);
+        if (need > 160 * 1024) use_mfma = false;         // (nwin 256 with more than ~100 kept rows: generic kernel)
+    }
+    if (use_mfma) {
+        // A[i][k] of v_mfma_f32_16x16x4_f32 for pass pz, tap n, k-step ks: lane l holds row i = l & 15, k = l >> 4.
+        // Row i: lane group gg = i >> 2 owns class pair m = 4 pz + gg: ca = m, cb = (m ? RQ - m : RQ / 2); sub = i & 3:
         // {ca re, ca im, cb re, cb im}.  Entry = component of
-        //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + 16 q] * exp(-2 pi i (r q / 8 + r n / 128)),  q = k + 4 h.
-        std::vector<float> at(32 * 64 + 6 * 64);          // A table, then the FAST epilogue's store offsets (ints)
-        for (int n = 0; n < 16; ++n)
-            for (int h = 0; h < 2; ++h)
-                for (int l = 0; l < 64; ++l) {
-                    const int i = l & 15, q = (l >> 4) + 4 * h;
-                    const int gg = i >> 2, sub = i & 3;
-                    const int r = (sub < 2) ? gg : (gg ? 8 - gg : 4);
-                    const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / 8.0 + static_cast<double>(r) * n / 128.0);
-                    const double c = std::cos(ang), sn = std::sin(ang);
-                    const double sg = (r & 1) ? -0.5 : 0.5;
-                    const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
-                    const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
-                    at[(n * 2 + h) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
-                }
+        //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + 16 q] * exp(-2 pi i (r q / RQ + r n / nwin)),  q = k + 4 ks.
+        const int rq = nwin / 16, npass = rq / 8, kst = rq / 4;
+        p->rq = rq;
+        const int atab_floats = hssfsst::core128_atab_floats(rq);
+        std::vector<float> at(atab_floats + 6 * 64);      // A table, then the FAST epilogue's store offsets (ints)
+        for (int pz = 0; pz < npass; ++pz)
+            for (int n = 0; n < 16; ++n)
+                for (int ks = 0; ks < kst; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = l & 15, q = (l >> 4) + 4 * ks;
+                        const int gg = i >> 2, sub = i & 3, m = 4 * pz + gg;
+                        const int r = (sub < 2) ? m : (m ? rq - m : rq / 2);
+                        const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / rq + static_cast<double>(r) * n / nwin);
+                        const double c = std::cos(ang), sn = std::sin(ang);
+                        const double sg = (r & 1) ? -0.5 : 0.5;
+                        const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
+                        const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
+                        at[(((pz * 16 + n) * kst) + ks) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
+                    }
         static_assert(sizeof(int) == sizeof(float), "offset table shares the float buffer");
         {
             int offs[6 * 64];
-            hssfsst::core128_store_offsets(p->klo, p->K > 0 ? p->K : 2, offs);
-            std::memcpy(at.data() + 32 * 64, offs, sizeof(offs));
+            hssfsst::core128_store_offsets(p->klo, p->K > 0 ? p->K : 2, offs, rq);
+            std::memcpy(at.data() + atab_floats, offs, sizeof(offs));
         }
         e = hipMalloc(reinterpret_cast<void**>(&p->d_atab), at.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice);

@@ -135,6 +135,17 @@ def test_nwin512_full_band_single_plane(oracle_mod, mode):
     _run_and_check(oracle_mod, X, 4000, w, None, abs_=(mode == "abs"), stack=(mode == "stack"), what=f"nwin512 full {mode}")
 
 
+@pytest.mark.parametrize("band,mode", [((25, 200), "stack"), ((25, 200), "abs"), ((30, 50), "stack"), ((0, 120), "raw"),
+                                       (None, "abs"), ((300, 500), "stack")])
+def test_nwin256_mfma_passes(oracle_mod, band, mode):
+    """nwin = 256 runs the MFMA kernel with a radix-16 first stage in two passes (classes {0,8,1,15,2,14,3,13}, then
+    {4,12,...,7,9}); wide bands that do not fit its LDS planes fall back to the generic kernel (band None)."""
+    from scipy.signal import get_window
+    w = get_window(("kaiser", 0.5), 256, fftbins=False)
+    X = np.concatenate([synth.pcg_windows(2, 900, seed=21), synth.noise_windows(2, 900, seed=22)])
+    _run_and_check(oracle_mod, X, 1000, w, band, abs_=(mode == "abs"), stack=(mode == "stack"), what=f"nwin256 {band} {mode}")
+
+
 def test_whole_recording(oracle_mod):
     # lazy dataset path: the transform gets a whole recording (heart_sounds.py:175-182)
     x = synth.recording(35500)
@@ -311,13 +322,20 @@ for B, n in ((96, 2000), (5, 777), (3, 4100)):
     outs.append(FSST(1000, w, truncate_freq=(25, 200), stack=True).batch(X).cpu().numpy())
     outs.append(FSST(1000, w, truncate_freq=(25, 200), abs=True).batch(X).cpu().numpy())
     outs.append(np.ascontiguousarray(FSST(1000, w).batch(X[:2]).cpu().numpy()).view(np.float32))
+# nwin = 256: MFMA kernel with two passes per group (generic kernel when forced)
+from scipy.signal import get_window
+w256 = get_window(("kaiser", 0.5), 256, fftbins=False)
+X = torch.from_numpy(synth.pcg_windows(7, 1500, seed=256)).cuda()
+outs.append(FSST(1000, w256, truncate_freq=(25, 200), stack=True).batch(X).cpu().numpy())
+outs.append(FSST(1000, w256, truncate_freq=(30, 50), stack=True).batch(X).cpu().numpy())      # K even <= 24: FAST epilogue
+outs.append(np.ascontiguousarray(FSST(1000, w256).batch(X[:2]).cpu().numpy()).view(np.float32))
 np.savez(sys.argv[1], *outs)
 '''
 
 
 def test_kernel_variants_agree(tmp_path):
     """The library's alternative execution paths must reproduce the default one: the 2-stream chunk
-    pipeline bit-exactly; the generic VALU kernel (forced for nwin = 128) to the parity tolerance."""
+    pipeline bit-exactly; the generic VALU kernel (forced for nwin = 128 and 256) to the parity tolerance."""
     paths = {}
     for tag, env in (("default", {}), ("piped", {"HSSFSST_CHUNKS": "3"}), ("generic", {"HSSFSST_FORCE_GENERIC": "1"})):
         out = str(tmp_path / f"{tag}.npz")
