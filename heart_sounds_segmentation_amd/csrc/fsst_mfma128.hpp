@@ -293,7 +293,11 @@ __device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot
 // RQ: radix of the first (matrix-pipe) stage, nwin = 16 RQ.  RQ = 8 is the canonical nwin = 128; RQ = 16 (nwin = 256)
 // runs the same 8-class structure twice per group of frames ("passes": classes {0,8,1,15,2,14,3,13}, then
 // {4,12,...,7,9}), each tap as a chain of RQ / 4 MFMA k-steps.
-template <int RQ, int FPW, bool FAST, int WPB>
+// S1C >= 0: the host guarantees that the kept band starts in stripe 0 and ends in stripe S1C (the canonical band
+// [25, 200] Hz at fs = 1000 is stripes 0..3 for every RQ); the per-source "does this stripe have a column in the own
+// plane" tests and their branches are then compile-time (measured 3.3-3.6 % of the kernel; making the whole band
+// (klo, K) a compile-time constant gave nothing more).  S1C = -1: any band.
+template <int RQ, int FPW, bool FAST, int WPB, int S1C>
 __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_core128_kernel(Core128Params p)
 {
     constexpr int NWIN = 16 * RQ, NPASS = RQ / 8, KST = RQ / 4;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const int K = p.K, klo = p.klo, n = p.n;
     const int LDF = plane_ldf(K);
     const int OLD = own_ld(klo, K, RQ);
-    const int s0 = own_s0(klo, RQ), s1 = own_s1(klo, K, RQ);
+    const int s0 = (S1C >= 0) ? 0 : own_s0(klo, RQ), s1 = (S1C >= 0) ? S1C : own_s1(klo, K, RQ);
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

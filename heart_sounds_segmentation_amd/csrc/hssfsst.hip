@@ -165,12 +165,12 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     return 0;
 }
 
-template <int RQ, bool FAST, int WPB>
+template <int RQ, bool FAST, int WPB, int S1C = -1>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
     const size_t lds = (hssfsst::core128_atab_floats(RQ) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ)) * sizeof(float);
-    auto kern = hssfsst::fsst_core128_kernel<RQ, kFpw128, FAST, WPB>;
+    auto kern = hssfsst::fsst_core128_kernel<RQ, kFpw128, FAST, WPB, S1C>;
     if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
         if (lds > 32 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -205,7 +205,11 @@ int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* parti
     const size_t fixed = (hssfsst::core128_atab_floats(rq) + hssfsst::kCtlFloats) * sizeof(float);
     const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq)) * sizeof(float);
     const size_t room = 160 * 1024;
+    // bands that start in stripe 0 of the own plane and end in stripe 3 (the canonical [25, 200] Hz at fs = 1000 for
+    // every radix) get kernels with compile-time stripe tests
+    const bool canon = hssfsst::own_s0(pl->klo, rq) == 0 && hssfsst::own_s1(pl->klo, pl->K, rq) == 3;
     if (rq == 8) {
+        if (fast && canon) return launch_core128_wpb<8, true, 16, 3>(pl, cp, nchunks, st);
         if (fast) return launch_core128_wpb<8, true, 16>(pl, cp, nchunks, st);       // K <= 24: 16 regions always fit
         if (fixed + 16 * per_wave <= room) return launch_core128_wpb<8, false, 16>(pl, cp, nchunks, st);
         if (fixed + 8 * per_wave <= room) return launch_core128_wpb<8, false, 8>(pl, cp, nchunks, st);
@@ -213,6 +217,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* parti
     } else {                                                                         // rq == 16, nwin = 256
         // (8 waves per block at most: two per SIMD, up to 256 VGPRs, no scratch)
         if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, true, 8>(pl, cp, nchunks, st);
+        if (!fast && canon && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, false, 8, 3>(pl, cp, nchunks, st);
         if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, false, 8>(pl, cp, nchunks, st);
         if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, false, 4>(pl, cp, nchunks, st);
         if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, true, 4>(pl, cp, nchunks, st);
