@@ -265,19 +265,27 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // the wave run the exact rounding path for it.  (Folding the 1/2 into the constants by doubling dw' saves
 // one more multiply per source, 1 % of the kernel, but doubles the cancellation error of V for far-moving
 // cells: measured 5 instead of 3 rounding flips per 918 k robust Hann columns, so it is not done.)
+// The two sources of one stripe (classes a and b of this lane) with ONE rare-path branch for both (a branch per
+// source -- v_cmp + s_and_saveexec + s_cbranch + s_or each -- measured 1.8 % slower; one branch per two stripes: no
+// further gain).
 template <int S, int RQ>
-__device__ __forceinline__ void process_source(f2 X, f2 P, f2 tiny, f2* own_slot, bool store, f2* row_disp,
-                                               int* flag, int klo, int K, int r)
+__device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 tiny, f2* ownA, f2* ownB, bool store,
+                                               f2* row_disp, int* flag, int klo, int K, int rA, int rB)
 {
-    const f2 t1 = mix_re(X, P);                         // (V.re, Vd'.im)
-    const f2 t2 = mix_im(X, P);                         // (V.im, Vd'.re)
-    const f2 dn = dn_second(t2, dn_first(t1, tiny));    // (den, num)
+    const f2 a1 = mix_re(XA, PA), a2 = mix_im(XA, PA);
+    const f2 b1 = mix_re(XB, PB), b2 = mix_im(XB, PB);
+    const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
     if (store) {                                        // wave-uniform predicate
-        float* q = reinterpret_cast<float*>(own_slot);
-        q[0] = t1.x; q[1] = t2.x;
+        float* qa = reinterpret_cast<float*>(ownA);
+        float* qb = reinterpret_cast<float*>(ownB);
+        qa[0] = a1.x; qa[1] = a2.x;
+        qb[0] = b1.x; qb[1] = b2.x;
     }
-    if (fabsf(dn.y) >= 0.5f * dn.x)                     // skipped when no lane moved (execz)
-        displaced_source<16 * RQ>(row_disp, flag, klo, K, r + RQ * S, dn.y, dn.x, f2{t1.x, t2.x});
+    const bool ma = fabsf(dna.y) >= 0.5f * dna.x, mb = fabsf(dnb.y) >= 0.5f * dnb.x;
+    if (ma | mb) {                                      // skipped when no lane moved (execz)
+        if (ma) displaced_source<16 * RQ>(row_disp, flag, klo, K, rA + RQ * S, dna.y, dna.x, f2{a1.x, a2.x});
+        if (mb) displaced_source<16 * RQ>(row_disp, flag, klo, K, rB + RQ * S, dnb.y, dnb.x, f2{b1.x, b2.x});
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,8 +473,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 PA = pb; PB = pa;
             }
             const bool st = (s >= s0) && (s <= s1);
-            process_source<s, RQ>(za[s], PA, tiny, ownA + RQ * s, st, row_disp, flag, klo, K, rAi);
-            process_source<s, RQ>(zb[s], PB, tiny, ownB + RQ * s, st, row_disp, flag, klo, K, rBi);
+            process_stripe<s, RQ>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, klo, K, rAi, rBi);
         });
         // k' = nwin/2 (class 0, j = 8) is its own partner: V = 2 Re(Z[nwin/2]) is real, its shift is exactly 0
         if constexpr (pz == 0) {
