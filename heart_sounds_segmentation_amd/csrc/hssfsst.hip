@@ -562,7 +562,11 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
             int64_t zgrid = zgrid_env > 0 ? zgrid_env : (piped ? 512 : 4096);
             // small batches: several blocks per signal, else one block per signal would leave most CUs idle
             int slices = 1;
-            if (zgrid_env <= 0 && !piped && cb < 1024) {
+            static const int zslices_env = std::getenv("HSSFSST_ZSLICES") ? std::atoi(std::getenv("HSSFSST_ZSLICES")) : 0;
+            if (zslices_env > 0) {
+                slices = zslices_env;
+                zgrid = cb * slices;
+            } else if (zgrid_env <= 0 && !piped && cb < 1024) {
                 slices = static_cast<int>(1024 / cb);
                 if (slices > 32) slices = 32;
             }
