@@ -1,5 +1,7 @@
 // fsst_mfma128.hpp -- second-generation synchrosqueeze core for the canonical window length
-// nwin = 128 (the reference's Kaiser(128) configuration, /root/reference/main.py:153-158).
+// nwin = 128 (the reference's Kaiser(128) configuration, /root/reference/main.py:153-158); the same kernel with a
+// radix-16 first stage in two passes also serves nwin = 256 (template parameter RQ = nwin / 16; the description
+// below is written for RQ = 8).
 //
 // Why a second kernel: measured on MI355X (profiles/r01_valu_ubench.txt) a 3-operand fp32 FMA
 // costs ~4 cycles per wave64 instruction, an add ~2.8, a PACKED v_pk_{add,mul,fma}_f32 ~4.3 for two
