@@ -1,7 +1,7 @@
 // fsst_mfma128.hpp -- second-generation synchrosqueeze core for the canonical window length
 // nwin = 128 (the reference's Kaiser(128) configuration, /root/reference/main.py:153-158); the same kernel with a
-// radix-16 first stage in two passes also serves nwin = 256 (template parameter RQ = nwin / 16; the description
-// below is written for RQ = 8).
+// radix-16 first stage in two passes also serves nwin = 256 and, with 32 taps, nwin = 512 (template parameters NT = taps,
+// RQ = first-stage radix, nwin = NT RQ; the description below is written for (16, 8)).
 //
 // Why a second kernel: measured on MI355X (profiles/r01_valu_ubench.txt) a 3-operand fp32 FMA
 // costs ~4 cycles per wave64 instruction, an add ~2.8, a PACKED v_pk_{add,mul,fma}_f32 ~4.3 for two
@@ -88,6 +88,15 @@ inline Core128Regions core128_regions(int ngroups)
     const int tail2 = ngroups >= 32 ? 6 : 0;             // groups wanted as 2-group chunks
     const int tail4 = ngroups >= 32 ? 16 : 0;            // groups wanted as 4-group chunks
 #endif
+    if (ngroups < 32) {
+        // short signals / streaming steps (a rolling transform adds 8 groups per step): parallelism matters more than
+        // the per-chunk overhead -- 2-group chunks up to 8 groups, 4-group chunks up to 31
+        const int gpc = ngroups <= 8 ? 2 : 4;
+        r.g0[0] = 0; r.gpc[0] = 8; r.npc[0] = 0;
+        r.g0[1] = 0; r.gpc[1] = 4; r.npc[1] = gpc == 4 ? (ngroups + 3) / 4 : 0;
+        r.g0[2] = 0; r.gpc[2] = 2; r.npc[2] = gpc == 2 ? (ngroups + 1) / 2 : 0;
+        return r;
+    }
     int big = ngroups - tail2 - tail4;
     big -= big % 8;                                      // whole 8-group chunks only
     if (big < 0) big = 0;
@@ -108,7 +117,13 @@ __device__ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.7071067811
 __device__ constexpr float kSin16[8] = {0.0f, 0.38268343236508978f, 0.70710678118654746f, 0.92387953251128674f,
                                         1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508984f};
 
+// (cos / sin of 2*pi*j/32 for the 32-tap variant, nwin = 512: kCos32 / kSin32 of fsst_kernels.hpp)
 constexpr __host__ __device__ int bitrev4(int n) { return ((n & 1) << 3) | ((n & 2) << 1) | ((n & 4) >> 1) | ((n & 8) >> 3); }
+template <int N>
+constexpr __host__ __device__ int bitrev_n(int n)
+{
+    return N == 16 ? bitrev4(n) : ((bitrev4(n & 15) << 1) | (n >> 4));        // N == 32: 5 bits
+}
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -145,17 +160,18 @@ __device__ __forceinline__ f2 sub_mi(f2 e, f2 o)         // e - (-i) o
 {
     f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(e), "v"(o)); return d;
 }
-// Radix-2 DIT butterfly on packed complex values, twiddle W = exp(-2*pi*i*TW/16).
-template <int TW>
-__device__ __forceinline__ void bfly16(f2& e, f2& o)
+// Radix-2 DIT butterfly on packed complex values, twiddle W = exp(-2*pi*i*TW/N), N = 16 or 32.
+template <int N, int TW>
+__device__ __forceinline__ void bfly_n(f2& e, f2& o)
 {
     f2 a, b;
     if constexpr (TW == 0) {
         a = e + o; b = e - o;
-    } else if constexpr (TW == 4) {                     // W = -i: W o = (o.im, -o.re)
+    } else if constexpr (TW == N / 4) {                 // W = -i: W o = (o.im, -o.re)
         a = add_mi(e, o); b = sub_mi(e, o);
     } else {                                            // W = wr + i wi, wr = cos, wi = -sin
-        constexpr float wr = kCos16[TW], wi = -kSin16[TW];
+        constexpr float wr = (N == 16) ? kCos16[TW & 7] : kCos32[TW & 15];
+        constexpr float wi = (N == 16) ? -kSin16[TW & 7] : -kSin32[TW & 15];
         const f2 t1 = pk_fma(f2{o.x, o.x}, f2{wr, wi}, e);
         a = pk_fma(f2{o.y, o.y}, f2{-wi, wr}, t1);      // e + W o
         b = pk_fma(e, f2{2.0f, 2.0f}, -a);              // e - W o = 2e - (e + W o)
@@ -163,20 +179,20 @@ __device__ __forceinline__ void bfly16(f2& e, f2& o)
     e = a; o = b;
 }
 
-// In-place 16-point complex FFT (forward); input in bit-reversed order, output natural order.
-// FIRST = 1 skips the first (twiddle-free) stage, which the caller has already applied.
-template <int FIRST = 0>
-__device__ __forceinline__ void fft16(f2 (&z)[16])
+// In-place N-point complex FFT (forward), N = 16 or 32; input in bit-reversed order, output natural order.
+template <int N>
+__device__ __forceinline__ void fft_n(f2 (&z)[N])
 {
-    static_for<4 - FIRST>([&](auto S) {
-        constexpr int L = 2 << (decltype(S)::value + FIRST);
+    constexpr int LOG2N = (N == 16) ? 4 : 5;
+    static_for<LOG2N>([&](auto S) {
+        constexpr int L = 2 << decltype(S)::value;
         constexpr int H = L / 2;
-        constexpr int STEP = 16 / L;
-        static_for<8>([&](auto B) {
+        constexpr int STEP = N / L;
+        static_for<N / 2>([&](auto B) {
             constexpr int b = decltype(B)::value;
             constexpr int j = b % H;
             constexpr int a = (b / H) * L + j;
-            bfly16<j * STEP>(z[a], z[a + H]);
+            bfly_n<N, j * STEP>(z[a], z[a + H]);
         });
     });
 }
@@ -196,8 +212,8 @@ __host__ __device__ constexpr int own_ld(int klo, int K, int rq = 8)
 {
     return odd_up(rq * (own_s1(klo, K, rq) - own_s0(klo, rq) + 1) + 1);
 }
-// MFMA A-operand constants: [pass][16 taps][k-step][64 lanes] floats, rq / 8 passes of rq / 4 k-steps
-__host__ __device__ constexpr int core128_atab_floats(int rq = 8) { return (rq / 8) * 16 * (rq / 4) * 64; }
+// MFMA A-operand constants: [pass][nt taps][k-step][64 lanes] floats, rq / 8 passes of rq / 4 k-steps
+__host__ __device__ constexpr int core128_atab_floats(int rq = 8, int nt = 16) { return (rq / 8) * nt * (rq / 4) * 64; }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
 constexpr int kCtlFloats = 4;                // block control words in LDS (chunk counter)
 
@@ -217,9 +233,9 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
             tab[(3 + i) * 64 + lane] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
         }
 }
-__host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8)
+__host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8, int nt = 16)
 {
-    return ((fpw + 16 * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4;   // + dirty flag
+    return ((fpw + nt * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4;   // + dirty flag
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -270,7 +286,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // The two sources of one stripe (classes a and b of this lane) with ONE rare-path branch for both (a branch per
 // source -- v_cmp + s_and_saveexec + s_cbranch + s_or each -- measured 1.8 % slower; one branch per two stripes: no
 // further gain).
-template <int S, int RQ>
+template <int S, int RQ, int NWIN>
 __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 tiny, f2* ownA, f2* ownB, bool store,
                                                f2* row_disp, int* flag, int klo, int K, int rA, int rB)
 {
@@ -285,8 +301,8 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
     }
     const bool ma = fabsf(dna.y) >= 0.5f * dna.x, mb = fabsf(dnb.y) >= 0.5f * dnb.x;
     if (ma | mb) {                                      // skipped when no lane moved (execz)
-        if (ma) displaced_source<16 * RQ>(row_disp, flag, klo, K, rA + RQ * S, dna.y, dna.x, f2{a1.x, a2.x});
-        if (mb) displaced_source<16 * RQ>(row_disp, flag, klo, K, rB + RQ * S, dnb.y, dnb.x, f2{b1.x, b2.x});
+        if (ma) displaced_source<NWIN>(row_disp, flag, klo, K, rA + RQ * S, dna.y, dna.x, f2{a1.x, a2.x});
+        if (mb) displaced_source<NWIN>(row_disp, flag, klo, K, rB + RQ * S, dnb.y, dnb.x, f2{b1.x, b2.x});
     }
 }
 
@@ -300,18 +316,19 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
 // FAST: the time-major [re | im] epilogue with 16-byte stores (mode STACK / STACK_UNNORM, K even, K <= 24 -- the
 // canonical configuration); otherwise the general epilogue (raw / abs / any K).  The host picks.
 // WPB: waves per block -- 16 (a whole CU) whenever 16 wave regions fit the 160 KB of LDS, else 8 / 4 / 2 / 1.
-// RQ: radix of the first (matrix-pipe) stage, nwin = 16 RQ.  RQ = 8 is the canonical nwin = 128; RQ = 16 (nwin = 256)
-// runs the same 8-class structure twice per group of frames ("passes": classes {0,8,1,15,2,14,3,13}, then
-// {4,12,...,7,9}), each tap as a chain of RQ / 4 MFMA k-steps.
+// NT, RQ: taps (= size of the per-lane FFT) and radix of the first (matrix-pipe) stage, nwin = NT RQ.  (16, 8) is the
+// canonical nwin = 128; (16, 16) = nwin 256 runs the same 8-class structure twice per group of frames ("passes":
+// classes {0,8,1,15,2,14,3,13}, then {4,12,...,7,9}), each tap as a chain of RQ / 4 MFMA k-steps; (32, 16) = nwin 512
+// does the same with 32 taps and 32-point FFTs per lane (two waves per SIMD, up to 256 VGPRs).
 // S1C >= 0: the host guarantees that the kept band starts in stripe 0 and ends in stripe S1C (the canonical band
 // [25, 200] Hz at fs = 1000 is stripes 0..3 for every RQ); the per-source "does this stripe have a column in the own
 // plane" tests and their branches are then compile-time (measured 3.3-3.6 % of the kernel; making the whole band
 // (klo, K) a compile-time constant gave nothing more).  S1C = -1: any band.
-template <int RQ, int FPW, bool FAST, int WPB, int S1C>
+template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C>
 __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_core128_kernel(Core128Params p)
 {
-    constexpr int NWIN = 16 * RQ, NPASS = RQ / 8, KST = RQ / 4;
-    constexpr int ATAB = core128_atab_floats(RQ);
+    constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
+    constexpr int ATAB = core128_atab_floats(RQ, NT);
     constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
     using avec = float __attribute__((ext_vector_type(KST)));          // one tap's A operand, all k-steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -326,9 +343,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
 #ifdef HSS_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
-    float* atab = smem;                                                      // [pass][16 taps][64 lanes][KST]
+    float* atab = smem;                                                      // [pass][NT taps][64 lanes][KST]
     int* next_q = reinterpret_cast<int*>(smem + ATAB);                       // block's chunk counter
-    float* wbase = smem + ATAB + kCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ);
+    float* wbase = smem + ATAB + kCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
@@ -406,8 +423,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         const int tg = t0 + grp * 16;
         const int tr = tg - p.col0;
         // the tile's LDS byte address as ONE opaque register: every tap is then an immediate offset of it
-        // (otherwise each merged ds_read2 gets its own "base + 0x2000 + tap" v_add)
-        unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + lane)));
+        // (otherwise each merged ds_read2 gets its own "base + 0x2000 + tap" v_add).  Lane (kk = lane >> 4, f = lane & 15)
+        // is row kk of the B operand for frame f: sample f + tap + NT (kk + 4 ks); for NT = 16 that is lane + tap + 64 ks.
+        unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + j + NT * g)));
         asm volatile("" : "+v"(xaddr));
         const lds_float* xb = (const lds_float*)static_cast<size_t>(xaddr);
         // ---- NPASS passes over the same 16 frames: pass pz handles class pairs 4 pz + g (pair 0 = the two
@@ -422,13 +440,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         const int rAi = pair, rBi = isg0 ? RQ / 2 : RQ - pair;
         f2* ownA = own_base + j * OLD + rAi - RQ * s0;       // column of k' = RQ s + rA at + RQ s
         f2* ownB = own_base + j * OLD + rBi - RQ * s0;
-        const float* myAp = myA + pz * 16 * 64 * KST;
+        const float* myAp = myA + pz * NT * 64 * KST;
 
-        // ---- folded window + radix-RQ stage on the matrix pipe: 16 taps x KST k-steps
-        f2 za[16], zb[16];
+        // ---- folded window + radix-RQ stage on the matrix pipe: NT taps x KST k-steps
+        f2 za[NT], zb[NT];
         // four taps at a time, k-step by k-step (the dependent MFMA of a tap is issued three MFMAs after the
         // previous k-step of the same tap; measured 1 % faster than tap by tap)
-        static_for<4>([&](auto GG) {
+        static_for<NT / 4>([&](auto GG) {
             constexpr int g0 = decltype(GG)::value * 4;
             f4 acc[4];
             avec a2[4];
@@ -442,31 +460,31 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<4>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][ks], xb[g0 + i + 64 * ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][ks], xb[g0 + i + 4 * NT * ks], acc[i], 0, 0, 0);
                 });
             });
             static_for<4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                za[bitrev4(g0 + i)] = f2{acc[i].x, acc[i].y};
-                zb[bitrev4(g0 + i)] = f2{acc[i].z, acc[i].w};
+                za[bitrev_n<NT>(g0 + i)] = f2{acc[i].x, acc[i].y};
+                zb[bitrev_n<NT>(g0 + i)] = f2{acc[i].z, acc[i].w};
             });
         });
 #if !defined(HSS_ABLATE) || HSS_ABLATE < 4
-        fft16(za);
-        fft16(zb);
+        fft_n<NT>(za);
+        fft_n<NT>(zb);
 #endif
 #if defined(HSS_ABLATE) && HSS_ABLATE >= 3
         {   // development only: keep the spectra alive without the source stage
             f2 acc = {0.0f, 0.0f};
-            static_for<16>([&](auto I) { acc += za[decltype(I)::value] + zb[decltype(I)::value]; });
+            static_for<NT>([&](auto I) { acc += za[decltype(I)::value] + zb[decltype(I)::value]; });
             if (s1 >= 0 && isg0) own_base[j * OLD] = acc;
         }
 #else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
-        static_for<8>([&](auto SS) {
+        static_for<NT / 2>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
-            // partner of a[s]: class 0 -> a[(16-s)&15];  else b[15-s].  partner of b[s]: class RQ/2 -> b[15-s]; else a[15-s]
-            const f2 pa0 = za[(16 - s) & 15], pb = zb[15 - s], pa = za[15 - s];
+            // partner of a[s]: class 0 -> a[(NT-s) mod NT];  else b[NT-1-s].  partner of b[s]: class RQ/2 -> b[NT-1-s]; else a[NT-1-s]
+            const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
             f2 PA, PB;
             if constexpr (pz == 0) {
                 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
@@ -475,11 +493,11 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 PA = pb; PB = pa;
             }
             const bool st = (s >= s0) && (s <= s1);
-            process_stripe<s, RQ>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, klo, K, rAi, rBi);
+            process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, klo, K, rAi, rBi);
         });
         // k' = nwin/2 (class 0, j = 8) is its own partner: V = 2 Re(Z[nwin/2]) is real, its shift is exactly 0
         if constexpr (pz == 0) {
-            if (s1 == 8 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[8].x, 0.0f};
+            if (s1 == NT / 2 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[NT / 2].x, 0.0f};
         }
 #endif
         });

@@ -122,7 +122,8 @@ struct hssfsst_plan {
     double fs = 0.0;
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
     float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
-    int rq = 0;                   // first-stage radix of the MFMA kernel (nwin / 16), 0 = generic kernel
+    int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
+    int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
     double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
@@ -165,12 +166,12 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     return 0;
 }
 
-template <int RQ, bool FAST, int WPB, int S1C = -1>
+template <int NT, int RQ, bool FAST, int WPB, int S1C = -1>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
-    const size_t lds = (hssfsst::core128_atab_floats(RQ) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
-                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ)) * sizeof(float);
-    auto kern = hssfsst::fsst_core128_kernel<RQ, kFpw128, FAST, WPB, S1C>;
+    const size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
+                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ, NT)) * sizeof(float);
+    auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, FAST, WPB, S1C>;
     if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
         if (lds > 32 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -201,26 +202,35 @@ int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* parti
     const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
                       (pl->K & 1) == 0 && pl->K <= 24;
     // waves per block: as many wave regions as fit the 160 KiB of LDS beside the shared tables
-    const int rq = pl->rq;
-    const size_t fixed = (hssfsst::core128_atab_floats(rq) + hssfsst::kCtlFloats) * sizeof(float);
-    const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq)) * sizeof(float);
+    const int rq = pl->rq, nt = pl->nt;
+    const size_t fixed = (hssfsst::core128_atab_floats(rq, nt) + hssfsst::kCtlFloats) * sizeof(float);
+    const size_t per_wave = static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq, nt)) * sizeof(float);
     const size_t room = 160 * 1024;
     // bands that start in stripe 0 of the own plane and end in stripe 3 (the canonical [25, 200] Hz at fs = 1000 for
-    // every radix) get kernels with compile-time stripe tests
+    // nwin 128 and 256) get kernels with compile-time stripe tests
     const bool canon = hssfsst::own_s0(pl->klo, rq) == 0 && hssfsst::own_s1(pl->klo, pl->K, rq) == 3;
-    if (rq == 8) {
-        if (fast && canon) return launch_core128_wpb<8, true, 16, 3>(pl, cp, nchunks, st);
-        if (fast) return launch_core128_wpb<8, true, 16>(pl, cp, nchunks, st);       // K <= 24: 16 regions always fit
-        if (fixed + 16 * per_wave <= room) return launch_core128_wpb<8, false, 16>(pl, cp, nchunks, st);
-        if (fixed + 8 * per_wave <= room) return launch_core128_wpb<8, false, 8>(pl, cp, nchunks, st);
-        if (fixed + 4 * per_wave <= room) return launch_core128_wpb<8, false, 4>(pl, cp, nchunks, st);
-    } else {                                                                         // rq == 16, nwin = 256
+    if (nt == 16 && rq == 8) {
+        if (fast && canon) return launch_core128_wpb<16, 8, true, 16, 3>(pl, cp, nchunks, st);
+        if (fast) return launch_core128_wpb<16, 8, true, 16>(pl, cp, nchunks, st);   // K <= 24: 16 regions always fit
+        if (fixed + 16 * per_wave <= room) return launch_core128_wpb<16, 8, false, 16>(pl, cp, nchunks, st);
+        if (fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 8, false, 8>(pl, cp, nchunks, st);
+        if (fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 8, false, 4>(pl, cp, nchunks, st);
+    } else if (nt == 16 && rq == 16) {                                               // nwin = 256
         // (8 waves per block at most: two per SIMD, up to 256 VGPRs, no scratch)
-        if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, true, 8>(pl, cp, nchunks, st);
-        if (!fast && canon && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, false, 8, 3>(pl, cp, nchunks, st);
-        if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, false, 8>(pl, cp, nchunks, st);
-        if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, false, 4>(pl, cp, nchunks, st);
-        if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, true, 4>(pl, cp, nchunks, st);
+        if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, true, 8>(pl, cp, nchunks, st);
+        if (!fast && canon && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, false, 8, 3>(pl, cp, nchunks, st);
+        if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, false, 8>(pl, cp, nchunks, st);
+        if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 16, false, 4>(pl, cp, nchunks, st);
+        if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 16, true, 4>(pl, cp, nchunks, st);
+    } else {                                                                         // nt == 32, rq == 16: nwin = 512
+        if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<32, 16, true, 8>(pl, cp, nchunks, st);
+        if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<32, 16, false, 8>(pl, cp, nchunks, st);
+        if (!fast && fixed + 6 * per_wave <= room) return launch_core128_wpb<32, 16, false, 6>(pl, cp, nchunks, st);
+        if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<32, 16, true, 4>(pl, cp, nchunks, st);
+        if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<32, 16, false, 4>(pl, cp, nchunks, st);
+        if (!fast && fixed + 3 * per_wave <= room) return launch_core128_wpb<32, 16, false, 3>(pl, cp, nchunks, st);
+        if (!fast && fixed + 2 * per_wave <= room) return launch_core128_wpb<32, 16, false, 2>(pl, cp, nchunks, st);
+        if (fast && fixed + 2 * per_wave <= room) return launch_core128_wpb<32, 16, true, 2>(pl, cp, nchunks, st);
     }
     return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B per wave exceeds the 160 KiB budget", per_wave);
 }
@@ -333,25 +343,26 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     e = hipMemcpy(p->d_ctab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(p->d_ctab); delete p; return fail(HSSFSST_EHIP, "plan_create: hipMemcpy: %s", hipGetErrorString(e)); }
     const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
-    static const bool mfma256 = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);     // A/B: nwin 256 on the generic kernel
-    bool use_mfma = (nwin == 128 || (nwin == 256 && mfma256)) && !(force && force[0] == '1');
-    if (use_mfma) {                                      // four wave regions of this band must fit beside the A table
-        const int rq0 = nwin / 16;
-        const size_t need = (hssfsst::core128_atab_floats(rq0) + hssfsst::kCtlFloats +
-                             4 * static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, p->klo, p->K, rq0))) * sizeof(float);
-        if (need > 160 * 1024) use_mfma = false;         // (nwin 256 with more than ~100 kept rows: generic kernel)
+    static const bool mfma_long = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);   // A/B: nwin 256 / 512 on the generic kernel
+    bool use_mfma = (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !(force && force[0] == '1');
+    const int nt0 = (nwin == 512) ? 32 : 16, rq0 = nwin / nt0;
+    if (use_mfma) {                                      // enough wave regions of this band must fit beside the A table
+        const int min_waves = (nwin == 512) ? 2 : 4;
+        const size_t need = (hssfsst::core128_atab_floats(rq0, nt0) + hssfsst::kCtlFloats + min_waves *
+                             static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, p->klo, p->K, rq0, nt0))) * sizeof(float);
+        if (need > 160 * 1024) use_mfma = false;         // (long windows with very wide bands: generic kernel)
     }
     if (use_mfma) {
         // A[i][k] of v_mfma_f32_16x16x4_f32 for pass pz, tap n, k-step ks: lane l holds row i = l & 15, k = l >> 4.
         // Row i: lane group gg = i >> 2 owns class pair m = 4 pz + gg: ca = m, cb = (m ? RQ - m : RQ / 2); sub = i & 3:
         // {ca re, ca im, cb re, cb im}.  Entry = component of
-        //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + 16 q] * exp(-2 pi i (r q / RQ + r n / nwin)),  q = k + 4 ks.
-        const int rq = nwin / 16, npass = rq / 8, kst = rq / 4;
-        p->rq = rq;
-        const int atab_floats = hssfsst::core128_atab_floats(rq);
+        //   C_r[n, q] = (-1)^r * 0.5 (w + i dw')[n + NT q] * exp(-2 pi i (r q / RQ + r n / nwin)),  q = k + 4 ks.
+        const int nt = nt0, rq = rq0, npass = rq / 8, kst = rq / 4;
+        p->rq = rq; p->nt = nt;
+        const int atab_floats = hssfsst::core128_atab_floats(rq, nt);
         std::vector<float> at(atab_floats + 6 * 64);      // A table, then the FAST epilogue's store offsets (ints)
         for (int pz = 0; pz < npass; ++pz)
-            for (int n = 0; n < 16; ++n)
+            for (int n = 0; n < nt; ++n)
                 for (int ks = 0; ks < kst; ++ks)
                     for (int l = 0; l < 64; ++l) {
                         const int i = l & 15, q = (l >> 4) + 4 * ks;
@@ -360,9 +371,9 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                         const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / rq + static_cast<double>(r) * n / nwin);
                         const double c = std::cos(ang), sn = std::sin(ang);
                         const double sg = (r & 1) ? -0.5 : 0.5;
-                        const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
+                        const double wv = window[n + nt * q], dv = dwb[n + nt * q];
                         const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
-                        at[(((pz * 16 + n) * kst) + ks) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
+                        at[(((pz * nt + n) * kst) + ks) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
                     }
         static_assert(sizeof(int) == sizeof(float), "offset table shares the float buffer");
         {
