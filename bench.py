@@ -160,7 +160,7 @@ def main():
                                    "Kaiser(128,0.5), band [25,200] Hz, stack=True -> (2000,44) fp32",
                        "windows_per_gpu": B, "clock_settle_steps": max(args.settle_steps, 0),
                        "parallelism": f"window-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "fsst_core128_kernel<8, 64, true, 16, 3>",
+            "roofline": {"bound": "hbm", "kernel": "fsst_core128_kernel<16, 8, 64, true, 16, 3>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic() if B == 1024 else None,
