@@ -590,8 +590,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 if (isabs) {
                     dst[4 * i] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
                 } else {
+#if defined(HSS_ABLATE) && HSS_ABLATE >= 1
+                    if (tg == 123456789)
+#endif
+                    {
                     dst[4 * i] = v.x;
                     dsti[4 * i] = v.y;
+                    }
                     st_s += v;
                     st_q = pk_fma(v, v, st_q);
                 }
