@@ -437,22 +437,30 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
         }
         const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
         float* base = out + static_cast<long long>(sig) * total;
-        if ((C & 3) == 0) {
-            // linear float4 sweep of the signal's block; the column of a chunk is tracked
-            // incrementally (no integer division in the loop)
+        if ((total & 3) == 0) {
+            // linear float4 sweep of the signal's block (its start is 16-byte aligned because total % 4 == 0); the
+            // column of a chunk is tracked incrementally (no integer division in the loop).  When 2K is not a
+            // multiple of 4 a float4 can wrap from the end of one row into the next: per-element wrap test.
             float4* b4 = reinterpret_cast<float4*>(base);
             const int tot4 = total >> 2;
             const int i0 = static_cast<int>(static_cast<long long>(tot4) * sl / slices);
             const int i1 = static_cast<int>(static_cast<long long>(tot4) * (sl + 1) / slices);
             int c = static_cast<int>((static_cast<unsigned>(i0 + tid) * 4u) % static_cast<unsigned>(C));
             const int dc = static_cast<int>(1024u % static_cast<unsigned>(C));
+            const bool rowwrap = (C & 3) != 0;
 #pragma unroll 4
             for (int i = i0 + tid; i < i1; i += 256) {
                 float4 v = b4[i];
-                v.x = (c + 0 < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
-                v.y = (c + 1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
-                v.z = (c + 2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
-                v.w = (c + 3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
+                int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+                if (rowwrap) {
+                    if (c1 >= C) c1 -= C;
+                    if (c2 >= C) c2 -= C;
+                    if (c3 >= C) c3 -= C;
+                }
+                v.x = (c < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+                v.y = (c1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+                v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+                v.w = (c3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
                 b4[i] = v;
                 c += dc;
                 if (c >= C) c -= C;
