@@ -351,6 +351,41 @@ def test_kernel_variants_agree(tmp_path):
         assert (colerr > parity.TOL * scale).mean() < 1e-3, ("generic", k, colerr.max(), scale)
 
 
+_SHARE_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from heart_sounds_segmentation_amd import FSST, synth
+seed = int(sys.argv[1])
+tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True)
+X = torch.from_numpy(synth.pcg_windows(300, 2000, seed=seed)).cuda()
+acc = None
+for rep in range(25):                                   # long enough for the two processes to overlap on the GPU
+    y = tf.batch(X)
+    acc = y if acc is None else acc
+    assert torch.equal(y, acc)
+np.save(sys.argv[2], acc[:8].cpu().numpy())
+'''
+
+
+def test_two_processes_share_the_gpu(tmp_path):
+    """DataLoader workers are separate processes on one GPU (main.py:206): the persistent core blocks of two
+    processes time-share the CUs; no block depends on another, so results stay identical and deterministic."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for seed in (501, 502):
+        out = str(tmp_path / f"share{seed}.npy")
+        procs.append((seed, out, subprocess.Popen([sys.executable, "-c", _SHARE_CHILD, str(seed), out], cwd=root,
+                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for seed, out, pr in procs:
+        log, _ = pr.communicate(timeout=600)
+        assert pr.returncode == 0, log
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    for seed, out, _ in procs:
+        alone = tf.batch(torch.from_numpy(synth.pcg_windows(300, 2000, seed=seed)).cuda())[:8].cpu().numpy()
+        assert np.array_equal(np.load(out), alone)
+
+
 def test_column_range_equals_full_transform():
     """hssfsst_exec_cols: a column sub-range equals the same columns of the whole-signal transform
     (un-normalised features and raw spectrum), for the MFMA kernel (nwin 128) and the generic one."""
