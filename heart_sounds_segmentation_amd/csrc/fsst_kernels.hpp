@@ -448,7 +448,10 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
             int c = static_cast<int>((static_cast<unsigned>(i0 + tid) * 4u) % static_cast<unsigned>(C));
             const int dc = static_cast<int>(1024u % static_cast<unsigned>(C));
             const bool rowwrap = (C & 3) != 0;
-#pragma unroll 4
+#ifndef HSS_NORM_UNROLL
+#define HSS_NORM_UNROLL 4
+#endif
+#pragma unroll HSS_NORM_UNROLL
             for (int i = i0 + tid; i < i1; i += 256) {
                 float4 v = b4[i];
                 int c1 = c + 1, c2 = c + 2, c3 = c + 3;
