@@ -33,6 +33,6 @@ out = [census("C2 pcg, Kaiser(128,0.5), stack", synth.pcg_windows(256, 2000), 10
        census("noise N(0,1), Kaiser(128,0.5), stack", synth.noise_windows(128, 2000), 1000, w, (25, 200), "stack"),
        census("noise, Kaiser(128,0.5), raw full", synth.noise_windows(32, 2000, seed=3), 1000, w, None, "raw"),
        census("noise, Hann(128), stack", synth.noise_windows(64, 2000, seed=4), 1000, get_window("hann", 128, fftbins=False), (25, 200), "stack"),
-       census("noise, Kaiser(256,10), abs (generic kernel)", synth.noise_windows(32, 2000, seed=5), 1000, get_window(("kaiser", 10.0), 256, fftbins=False), (25, 200), "abs"),
-       census("pcg 4 kHz, Kaiser(512,0.5), stack (generic kernel)", synth.pcg_windows(32, 4000, fs=4000, seed=6), 4000, get_window(("kaiser", 0.5), 512, fftbins=False), (25, 200), "stack")]
+       census("noise, Kaiser(256,10), abs (MFMA kernel, two passes)", synth.noise_windows(32, 2000, seed=5), 1000, get_window(("kaiser", 10.0), 256, fftbins=False), (25, 200), "abs"),
+       census("pcg 4 kHz, Kaiser(512,0.5), stack (MFMA kernel, 32 taps)", synth.pcg_windows(32, 4000, fs=4000, seed=6), 4000, get_window(("kaiser", 0.5), 512, fftbins=False), (25, 200), "stack")]
 print(json.dumps(out, indent=1))
