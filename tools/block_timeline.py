@@ -41,3 +41,11 @@ if os.environ.get("BY_RANK"):
     for r in range(0, (nblocks + 255) // 256):
         m = (idx // 256) == r
         print(f"blockIdx / 256 == {r}: start mean {s[m].mean():6.1f}  end mean {e[m].mean():6.1f} (p5 {np.percentile(e[m], 5):6.1f}, p95 {np.percentile(e[m], 95):6.1f}) us")
+if os.environ.get("BY_BLOCK"):
+    wpb = int(os.environ["BY_BLOCK"]); idx = np.nonzero(ok)[0]
+    nb = nblocks // wpb
+    bend = np.array([e[(idx // wpb) == b].max() for b in range(nb)]); bmin = np.array([e[(idx // wpb) == b].min() for b in range(nb)])
+    print(f"per block of {wpb} waves: last-wave end  mean {bend.mean():.1f}  p5 {np.percentile(bend, 5):.1f}  p95 {np.percentile(bend, 95):.1f}  max {bend.max():.1f} us; "
+          f"first-to-last wave end inside a block: mean {np.mean(bend - bmin):.1f} us")
+    for x in range(8):
+        print(f"  blocks with blockIdx % 8 == {x}: last-wave end mean {bend[np.arange(nb) % 8 == x].mean():.1f} us")
