@@ -62,6 +62,28 @@ def cpu_baseline(X, w, budget_s=12.0):
                       f"(oracle/fsst_oracle.c), OpenMP over windows on {threads} of {cores} host cores"}
 
 
+def self_launch(ngpus: int) -> int:
+    """Re-exec this command under torch.distributed.run with `ngpus` ranks on this node; fails loudly when fewer
+    GPUs are visible (never a silent 1-rank run that reports n_gpus = N)."""
+    import socket
+    import subprocess
+
+    import torch
+    have = torch.cuda.device_count()
+    if have < ngpus:
+        print(f"bench.py: --gpus {ngpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +96,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # N > 1 without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1),
+    # exactly as the driver would:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -82,6 +111,10 @@ def main():
     from heart_sounds_segmentation_amd import FSST, dist as hdist, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("HSS_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test

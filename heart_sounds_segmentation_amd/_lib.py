@@ -25,7 +25,9 @@ _lib = None
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/hssfsst.hip for gfx950 into libhssfsst.so (cross-compiles without a GPU)."""
-    deps = [SRC, os.path.join(_PKG, "csrc", "fsst_kernels.hpp"), HEADER]
+    csrc = os.path.join(_PKG, "csrc")
+    # every source under csrc/ (the MFMA core, the generic kernels, the host helpers) plus the C header
+    deps = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".h"))) + [HEADER]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
@@ -68,6 +70,8 @@ def lib():
         L.hssfsst_exec.restype = c_int
         L.hssfsst_exec_cols.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, c_int, vp, c_int, vp]
         L.hssfsst_exec_cols.restype = c_int
+        L.hssfsst_exec_frames.argtypes = [vp, vp, c_i64, c_int, c_i64, c_int, c_int, c_int, vp, c_int, vp]
+        L.hssfsst_exec_frames.restype = c_int
         L.hssfsst_normalize_running.argtypes = [vp, vp, c_i64, c_int, vp, vp]
         L.hssfsst_normalize_running.restype = c_int
         L.hssfsst_plan_set_timing.argtypes = [vp, c_int]
@@ -96,11 +100,12 @@ def lib():
 
 
 def check(rc: int, what: str) -> None:
-    """Status -> exception: bad arguments raise ValueError, everything else RuntimeError (the
-    reference's dataset only catches RuntimeError, hss/datasets/heart_sounds.py:183)."""
+    """Status -> exception: bad arguments raise ValueError, everything else -- including a
+    configuration the kernels cannot run (E_UNSUPPORTED) -- RuntimeError, the one exception the
+    reference's dataset catches around the transform (hss/datasets/heart_sounds.py:183)."""
     if rc == 0:
         return
     msg = lib().hssfsst_last_error().decode("utf-8", "replace")
-    if rc in (E_INVAL, E_UNSUPPORTED):
+    if rc == E_INVAL:
         raise ValueError(f"{what}: {msg} (status {rc})")
     raise RuntimeError(f"{what}: {msg} (status {rc})")

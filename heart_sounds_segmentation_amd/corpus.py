@@ -1,37 +1,61 @@
 """Batched counterpart of the reference's in-memory dataset loop:
 ``DavidSpringerHSS.__init__`` (/root/reference/hss/datasets/heart_sounds.py:155-169) turns every
 recording into frames (``frame_signal``, stride 1000, length 2000) and calls the transform once per
-frame on the CPU.  Here a recording's frames go to the GPU as ONE strided view and one launch.
+frame on the CPU.  Here a recording is uploaded ONCE and its overlapping frames are read in place by
+one launch (``hssfsst_exec_frames``: no 2x duplicated H2D copy, no materialised frame matrix).
 
 Semantics kept (pinned by tests/golden/frame_signal.npz): recordings shorter than ``frame_len`` are
 skipped (heart_sounds.py:161-162); ``L = floor((T - n)/stride)`` frames -- one fewer than fit --
 (preprocess.py:40,48-52); labels are shifted to 0-based (``y - 1``, heart_sounds.py:164) and framed
 identically; each item is ``(features (n, 2K) float32, labels (n,) int64)`` (heart_sounds.py:168).
+
+Multi-GPU (BASELINE config C3): ``rank`` / ``world`` split the RECORDINGS in contiguous
+blocks (``dist.shard_bounds``), so framing stays local to a rank and concatenating the ranks' item lists in rank
+order is the single-process list; ``gather_features`` reassembles the feature tensor on every rank with one
+(ragged) RCCL all-gather.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Tuple
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import dist as hdist
 from .framing import frame_batch
+
+Item = Tuple[torch.Tensor, Optional[torch.Tensor]]
 
 
 def build_features(recordings: Iterable[Tuple[torch.Tensor, Optional[torch.Tensor]]], fsst,
                    stride: int = 1000, frame_len: int = 2000, device: Optional[torch.device] = None,
-                   keep_on_device: bool = False) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
+                   keep_on_device: bool = False, rank: Optional[int] = None,
+                   world: Optional[int] = None) -> List[Item]:
     """``recordings``: iterable of ``(x (T,) float32, y (T,) int64 labels in 1..4 or None)``.
-    Returns the list the reference dataset would hold in ``self.data`` (``in_memory=True, framing=True``)."""
-    items: List[Tuple[torch.Tensor, Optional[torch.Tensor]]] = []
+    Returns the list the reference dataset would hold in ``self.data`` (``in_memory=True, framing=True``);
+    with ``world`` > 1 only the part of it that comes from this rank's block of recordings."""
+    items: List[Item] = []
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if world is not None and world > 1:
+        recs: Sequence = recordings if isinstance(recordings, (list, tuple)) else list(recordings)
+        lo, hi = hdist.shard_bounds(len(recs), int(world), int(rank or 0))
+        recordings = recs[lo:hi]
     for x, y in recordings:
         if x.shape[0] < frame_len:
             continue
-        frames = frame_batch(x.to(torch.float32), stride, frame_len)          # (L, n) view
-        feats = fsst.batch(frames.to(dev))                                   # (L, n, 2K) on the GPU
+        xd = x.reshape(-1).to(device=dev, dtype=torch.float32)                 # ONE upload of the recording
+        feats = fsst.batch(frame_batch(xd, stride, frame_len))                 # (L, n, 2K); frames read in place
         if not keep_on_device:
             feats = feats.cpu()
         labels = frame_batch((y - 1), stride, frame_len) if y is not None else None
         for i in range(feats.shape[0]):
             items.append((feats[i], labels[i].clone() if labels is not None else None))
     return items
+
+
+def gather_features(items: List[Item], group=None) -> torch.Tensor:
+    """Stack this rank's features and all-gather them (rank order == recording order) into the full
+    ``(windows, n, 2K)`` tensor on every rank.  Without an initialised process group: just the stack."""
+    if not items:
+        raise ValueError("gather_features: this rank holds no items (give every rank at least one recording)")
+    local = torch.stack([f for f, _ in items], dim=0)
+    return hdist.all_gather_ragged(local, group)

@@ -49,6 +49,8 @@ struct CoreParams {
     int col0;             // first output column (frame centre) of every signal
     int ncols;            // number of output columns (== n for a whole-signal transform)
     int oneplane;         // 1: own and displaced values share one LDS plane (wide bands)
+    long long xstride;    // samples between the starts of consecutive signals (n for a dense batch; smaller for
+                          // overlapping frames of one recording, hss/utils/preprocess.py:48-52)
 };
 
 // Window tables are read-only for the whole launch and indexed wave-uniformly: the constant
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const int n = p.n;
     const int ncols = p.ncols, tr0 = t0 - p.col0;      // output rows are relative to col0
     const int K = p.K;
-    const float* xsig = p.x + b * static_cast<long long>(n);
+    const float* xsig = p.x + b * p.xstride;
 
     // stage the zero-padded signal tile: xs[i] = xpad[t0 + i] = x[t0 + i - nwin/2]
     for (int i = tid; i < TILE + NWIN - 1; i += TILE) {

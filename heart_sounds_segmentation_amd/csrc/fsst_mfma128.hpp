@@ -70,6 +70,7 @@ struct Core128Params {
     int nsig;             // signals in this launch
     int col0;             // first output column (frame centre) of every signal
     int ncols;            // number of output columns (== n for a whole-signal transform)
+    long long xstride;    // samples between the starts of consecutive signals (n for a dense batch)
     Core128Regions reg;
 };
 
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const int grp0 = p.reg.g0[rg] + cidx * gpc;
     const int ngrp = min(gpc, ngroups - grp0);
     const int slot = ((rg > 0) ? p.reg.npc[0] : 0) + ((rg > 1) ? p.reg.npc[1] : 0) + cidx;
-    const float* xsig = p.x + b * static_cast<long long>(n);
+    const float* xsig = p.x + b * p.xstride;
     auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
         for (int i = lane; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;

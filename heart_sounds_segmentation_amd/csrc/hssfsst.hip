@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -39,6 +40,29 @@ int fail(int code, const char* fmt, ...)
             return fail(HSSFSST_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// Makes `device` current for the scope and restores the caller's device on every exit path (a process
+// that drives several GPUs must not find its current HIP device changed by a library call).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_SCOPE(dev)                                                                      \
+    DeviceGuard device_guard_(dev);                                                            \
+    if (device_guard_.err != hipSuccess)                                                       \
+        return fail(HSSFSST_EHIP, "selecting device %d failed: %s", (dev), hipGetErrorString(device_guard_.err))
 
 // Knot slopes of the not-a-knot cubic spline through (1..n, w): the derivative window of
 // ssq.fsst's instantaneous-frequency estimator before its fs/(2*pi) scaling (MATLAB fsst.m, local
@@ -139,6 +163,20 @@ struct hssfsst_plan {
 
 namespace {
 
+// The dynamic-LDS limit is a property of the kernel instantiation (per device), not of a plan: raise it ONCE to
+// the full 160 KiB, so that plans with different band widths sharing an instantiation cannot lower it under each
+// other and the hot path makes no driver call for it.
+constexpr int kMaxLdsBytes = 160 * 1024;
+template <class Kern>
+int allow_full_lds(Kern kern, int device, std::atomic<unsigned long long>& done)
+{
+    const unsigned long long bit = 1ull << (device & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 int out_floats_per_sample(const hssfsst_plan* p) { return p->mode == HSSFSST_MODE_ABS ? p->K : 2 * p->K; }
 
 template <int R>
@@ -158,9 +196,8 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     }
     if (lds > 160 * 1024) return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B exceeds 160 KiB", lds);
     auto kern = hssfsst::fsst_core_kernel<R, kTile>;
-    if (lds > 32 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kTile), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -172,10 +209,9 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     const size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ, NT)) * sizeof(float);
     auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, FAST, WPB, S1C>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
-        if (lds > 32 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         int per_cu = 0, cus = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
@@ -190,10 +226,11 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     return 0;
 }
 
-int launch_core128(hssfsst_plan* pl, const float* dx, float* dout, double* partials, int n, int col0, int ncols,
-                   int64_t batch, hipStream_t st)
+int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* dout, double* partials, int n, int col0,
+                   int ncols, int64_t batch, hipStream_t st)
 {
     hssfsst::Core128Params cp;
+    cp.xstride = xstride;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = static_cast<int>(batch);
     cp.col0 = col0; cp.ncols = ncols;
@@ -301,7 +338,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     }
     if (device < 0 || device >= ndev) return fail(HSSFSST_EINVAL, "plan_create: device %d out of range [0,%d)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    DEVICE_SCOPE(device);
 
     hssfsst_plan* p = new (std::nothrow) hssfsst_plan();
     if (!p) return fail(HSSFSST_ENOMEM, "plan_create: host allocation failed");
@@ -396,7 +433,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
 int hssfsst_plan_destroy(hssfsst_plan* p)
 {
     if (!p) return 0;
-    (void)hipSetDevice(p->device);
+    DeviceGuard device_guard_(p->device);
     if (p->d_ctab) (void)hipFree(p->d_ctab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
@@ -439,7 +476,7 @@ int hssfsst_plan_timing(hssfsst_plan* p, float ms_sum[2], int* nexec)
     ms_sum[0] = ms_sum[1] = 0.0f;
     *nexec = static_cast<int>(p->ev_chunks.size());
     if (p->ev_used == 0) return 0;
-    HIP_TRY(hipSetDevice(p->device));
+    DEVICE_SCOPE(p->device);
     HIP_TRY(hipEventSynchronize(p->ev[p->ev_used - 1]));
     size_t i = 0;
     for (int nc : p->ev_chunks) {
@@ -466,11 +503,18 @@ int hssfsst_exec(hssfsst_plan* p, const float* x, int64_t batch, int n, int x_on
 int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int col0, int ncols, int x_on_device,
                       float* out, int out_on_device, void* stream)
 {
-    if (!p || !x || !out || batch < 0 || n < 1 || col0 < 0 || ncols < 1 || col0 > n - ncols)
-        return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d col0=%d ncols=%d)", static_cast<long long>(batch), n, col0, ncols);
+    return hssfsst_exec_frames(p, x, batch, n, static_cast<int64_t>(n), col0, ncols, x_on_device, out, out_on_device, stream);
+}
+
+int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
+                        int x_on_device, float* out, int out_on_device, void* stream)
+{
+    if (!p || !x || !out || batch < 0 || n < 1 || col0 < 0 || ncols < 1 || col0 > n - ncols || x_stride < 1)
+        return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d stride=%lld col0=%d ncols=%d)",
+                    static_cast<long long>(batch), n, static_cast<long long>(x_stride), col0, ncols);
     if (batch == 0 || p->K == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(p->device));
+    DEVICE_SCOPE(p->device);
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
     // statistics partials per signal: one per chunk (nwin 128) / per 64-frame tile (generic kernel)
@@ -479,7 +523,9 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
-    const size_t nx = static_cast<size_t>(batch) * n, no = static_cast<size_t>(batch) * ncols * ofps;
+    // input extent: `batch` signals of n samples whose starts are x_stride apart (they may overlap)
+    const size_t nx = static_cast<size_t>(batch > 0 ? batch - 1 : 0) * static_cast<size_t>(x_stride) + n;
+    const size_t no = static_cast<size_t>(batch) * ncols * ofps;
 
     const float* dx = x;
     float* dout = out;
@@ -540,16 +586,16 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
     int ci = 0;
     for (int64_t c0 = 0; c0 < batch; c0 += chunk, ++ci) {
         const int64_t cb = (batch - c0 < chunk) ? batch - c0 : chunk;
-        const float* cx = dx + c0 * n;
+        const float* cx = dx + c0 * x_stride;
         float* cout = dout + c0 * per;
         hssfsst::CoreParams cp;
         cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * 4 : nullptr; cp.ctab = p->d_ctab;
-        cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols;
+        cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols; cp.xstride = x_stride;
         const long long cblocks = static_cast<long long>(cb) * nblk;
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         if (use128) {
-            rc = launch_core128(p, cx, cout, cp.partials, n, col0, ncols, cb, st);
+            rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
@@ -617,7 +663,7 @@ int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, in
     if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "moments_merge: bad argument");
     if (batch == 0 || p->K == 0) return 0;
     if (batch > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "moments_merge: batch too large");
-    HIP_TRY(hipSetDevice(p->device));
+    DEVICE_SCOPE(p->device);
     hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), feats, state, n, p->K);
     HIP_TRY(hipGetLastError());
@@ -670,7 +716,7 @@ int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int 
     if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "normalize_running: bad argument");
     if (batch == 0 || p->K == 0) return 0;
     if (batch > 0x7fffffffLL || static_cast<long long>(n) * 2 * p->K >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "normalize_running: too large");
-    HIP_TRY(hipSetDevice(p->device));
+    DEVICE_SCOPE(p->device);
     int rc;
     if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -51,6 +51,23 @@ def all_gather_blocks(local: torch.Tensor, total: int, group: Optional[dist.Proc
     counts = [h - l for l, h in sizes]
     if local.shape[0] != counts[rank]:
         raise ValueError(f"all_gather_blocks: local block has {local.shape[0]} rows, expected {counts[rank]}")
+    return _gather_counts(local, counts, group)
+
+
+def all_gather_ragged(local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """All-gather blocks whose row counts are only known locally (recording-level corpus split: the number of
+    windows per rank depends on the recording lengths): one tiny all-gather of the counts, then the payload."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    allc = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    return _gather_counts(local, [int(c) for c in allc.tolist()], group)
+
+
+def _gather_counts(local: torch.Tensor, counts, group) -> torch.Tensor:
+    world, total = len(counts), sum(counts)
     tail = tuple(local.shape[1:])
     local = local.contiguous()
     if len(set(counts)) == 1:

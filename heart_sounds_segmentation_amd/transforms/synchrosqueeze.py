@@ -132,9 +132,13 @@ class FSST:
     # ------------------------------------------------------------------ execution
     def _run(self, X: torch.Tensor, mode: Optional[int] = None,
              out: Optional[torch.Tensor] = None, cols: Optional[tuple] = None) -> torch.Tensor:
-        """X: (B, n) float32 contiguous, CPU or cuda.  Returns per-mode tensor on X's device.
-        cols = (col0, ncols) restricts the output to those frame centres."""
+        """X: (B, n) float32, CPU or cuda, unit stride along n and a positive stride between signals (a dense
+        batch, or overlapping frames of one recording as made by framing.frame_batch -- read in place).
+        Returns per-mode tensor on X's device.  cols = (col0, ncols) restricts the output to those frame centres."""
         B, n_in = X.shape
+        xstride = int(X.stride(0)) if B > 1 else int(n_in)
+        if n_in > 1 and X.stride(1) != 1:
+            raise ValueError("FSST: samples of a signal must be contiguous")
         col0, n = cols if cols is not None else (0, n_in)
         if col0 < 0 or n < 1 or col0 + n > n_in:
             raise ValueError(f"FSST: column range ({col0}, {n}) outside a signal of {n_in} samples")
@@ -160,20 +164,25 @@ class FSST:
         if B == 0 or K == 0:
             return out
         stream = torch.cuda.current_stream(dev).cuda_stream if on_dev else None
-        rc = _lib.lib().hssfsst_exec_cols(plan.handle, ctypes.c_void_p(X.data_ptr()), int(B), int(n_in),
-                                          int(col0), int(n), 1 if on_dev else 0,
-                                          ctypes.c_void_p(out.data_ptr()), 1 if on_dev else 0,
-                                          ctypes.c_void_p(stream) if stream else None)
-        _lib.check(rc, "hssfsst_exec_cols")
+        rc = _lib.lib().hssfsst_exec_frames(plan.handle, ctypes.c_void_p(X.data_ptr()), int(B), int(n_in), xstride,
+                                            int(col0), int(n), 1 if on_dev else 0,
+                                            ctypes.c_void_p(out.data_ptr()), 1 if on_dev else 0,
+                                            ctypes.c_void_p(stream) if stream else None)
+        _lib.check(rc, "hssfsst_exec_frames")
         return out
 
     @staticmethod
-    def _as_f32(x: torch.Tensor) -> torch.Tensor:
+    def _as_f32(x: torch.Tensor, frames: bool = False) -> torch.Tensor:
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x))
         if x.is_complex():
             raise ValueError("FSST: real input expected")
-        return x.detach().to(torch.float32).contiguous()
+        x = x.detach().to(torch.float32)
+        # frames=True: a (B, n) view with unit stride along n and a positive signal stride is read in place
+        # (overlapping frames of one recording: no duplicated copy); anything else is made dense
+        if frames and x.ndim == 2 and x.shape[1] > 1 and x.stride(1) == 1 and (x.shape[0] <= 1 or x.stride(0) >= 1):
+            return x
+        return x.contiguous()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         """
@@ -197,7 +206,7 @@ class FSST:
         """Extension: transform ``B`` independent signals at once.  ``X``: ``(B, n)`` (CPU or cuda).
         Returns ``(B, n, 2K)`` / ``(B, n, K)`` / complex64 ``(B, K, n)`` on X's device; a CPU input
         is staged through the device by the library.  ``out`` optionally receives the result."""
-        X = self._as_f32(X)
+        X = self._as_f32(X, frames=True)
         if X.ndim == 3 and X.shape[-1] == 1:
             X = X[..., 0]
         if X.ndim != 2:
@@ -223,7 +232,7 @@ class FSST:
         """Extension (streaming): ``(B, n, 2K)`` [real | imag] features
         WITHOUT the per-signal z-score, for use with running moments.  ``cols=(col0, ncols)``
         computes only those frame centres."""
-        X = self._as_f32(X)
+        X = self._as_f32(X, frames=True)
         if X.ndim == 1:
             X = X.unsqueeze(0)
         return self._run(X, _lib.MODE_STACK_UNNORM, cols=cols)

@@ -78,6 +78,14 @@ int hssfsst_exec(hssfsst_plan* plan, const float* x, int64_t batch, int n, int x
 int hssfsst_exec_cols(hssfsst_plan* plan, const float* x, int64_t batch, int n, int col0, int ncols,
                       int x_on_device, float* out, int out_on_device, void* stream);
 
+/* Framed variant: the `batch` signals are views of ONE buffer whose starts are x_stride samples apart
+ * (x_stride < n: overlapping frames).  Replaces the reference's framing + per-frame transform loop
+ * (hss/utils/preprocess.py:40-52 frame_signal -> hss/datasets/heart_sounds.py:166-168): a recording is uploaded once
+ * and its stride-1000 / length-2000 frames are read in place.  x spans (batch-1)*x_stride + n floats.
+ * hssfsst_exec_cols(...) == hssfsst_exec_frames(..., x_stride = n, ...). */
+int hssfsst_exec_frames(hssfsst_plan* plan, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
+                        int x_on_device, float* out, int out_on_device, void* stream);
+
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
  * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the
