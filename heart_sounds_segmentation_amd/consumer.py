@@ -32,6 +32,29 @@ class SegmenterHead(nn.Module):
         self.register_buffer("h0", h0 if h0 is not None else torch.randn(shape), persistent=False)
         self.register_buffer("c0", c0 if c0 is not None else torch.randn(shape), persistent=False)
 
+    @classmethod
+    def seeded_like_reference(cls, seed: int, input_size: int = 44, hidden_size: int = 240,
+                              batch_size: int = 50) -> "SegmenterHead":
+        """The module the reference constructor would build under ``torch.manual_seed(seed)``: it draws h0, c0
+        first, then initialises lstm_1, lstm_2 and linear (segmenter.py:38-67); same draws, same order here, so a
+        fixture only needs the seed and a checksum of the weights (tests/golden/segmenter_c4.npz)."""
+        torch.manual_seed(seed)
+        shape = (2, batch_size, hidden_size)
+        h0, c0 = torch.randn(shape), torch.randn(shape)
+        return cls(input_size, hidden_size, batch_size, h0=h0, c0=c0)
+
+    def checksum(self) -> bytes:
+        """SHA-256 over the state_dict (sorted keys) and h0 / c0, as written by tests/golden/make_golden.py."""
+        import hashlib
+        h = hashlib.sha256()
+        sd = self.state_dict()
+        for k in sorted(sd.keys()):
+            h.update(k.encode())
+            h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+        h.update(self.h0.detach().cpu().numpy().tobytes())
+        h.update(self.c0.detach().cpu().numpy().tobytes())
+        return h.digest()
+
     def forward(self, feats: torch.Tensor) -> torch.Tensor:
         y, carry = self.lstm_1(feats, (self.h0, self.c0))
         y, _ = self.lstm_2(self.drop(torch.relu(y)), carry)

@@ -165,5 +165,43 @@ def main():
     print("segmenter", sorted(m.state_dict().keys())[:3], yout.shape)
 
 
+def segmenter_c4():
+    """BASELINE config C4 at its real size: the reference pipeline end to end on the CPU -- the reference FSST class
+    (wrapper over the oracle core, main.py:153-158 configuration) on 50 synthetic 2000-sample windows, then the
+    reference ``HeartSoundSegmenter(input_size=44, batch_size=50)`` (hidden 240, main.py:170,221) in eval mode.
+    The 1.94 M weights are NOT stored (7.7 MB of noise): they are a function of the seed and of the construction
+    order of the reference class (h0, c0, lstm_1, lstm_2, linear -- segmenter.py:38-67), which the test replays;
+    a SHA-256 of the state_dict pins that the replay produced the same numbers."""
+    import hashlib
+    shim = types.ModuleType("ssq")
+    shim.fsst = lambda x, fs, window: oracle.fsst(x, fs, window)
+    sys.modules["ssq"] = shim
+    ref_ss = _load("ref_synchrosqueeze", os.path.join(REF, "hss/transforms/synchrosqueeze.py"))
+    ref_seg = _load("ref_segmenter", os.path.join(REF, "hss/model/segmenter.py"))
+    seed, wseed, B, n = 4242, 44, 50, 2000
+    kaiser = synth.kaiser_window(128, 0.5)
+    X = synth.pcg_windows(B, n, seed=wseed)
+    tf = ref_ss.FSST(1000, kaiser, truncate_freq=(25, 200), stack=True)
+    feats = torch.stack([tf(torch.from_numpy(X[b]).reshape(n, 1)).contiguous() for b in range(B)])
+    torch.manual_seed(seed)
+    m = ref_seg.HeartSoundSegmenter(input_size=44, batch_size=B)
+    m.eval()
+    with torch.no_grad():
+        y = m(feats)
+    h = hashlib.sha256()
+    for k in sorted(m.state_dict().keys()):
+        h.update(k.encode())
+        h.update(m.state_dict()[k].contiguous().numpy().tobytes())
+    h.update(m.h0.numpy().tobytes())
+    h.update(m.c0.numpy().tobytes())
+    np.savez_compressed(os.path.join(HERE, "segmenter_c4.npz"), y=y.numpy(), seed=np.int64(seed), window_seed=np.int64(wseed),
+                        sha256=np.frombuffer(h.digest(), dtype=np.uint8), feat_probe=feats[:, ::250, :].numpy())
+    print("segmenter_c4", tuple(feats.shape), "->", tuple(y.shape), h.hexdigest()[:16])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "c4":
+        segmenter_c4()
+        sys.exit(0)
     main()
+    segmenter_c4()

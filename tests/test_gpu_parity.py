@@ -462,6 +462,32 @@ def test_corpus_builder_and_end_to_end(oracle_mod):
     assert (lp.exp().sum(-1) - 1).abs().max() < 1e-4
 
 
+def test_c4_end_to_end_matches_reference_pipeline():
+    """BASELINE config C4 at its real size (batch 50, hidden 240, 2000 steps): HIP FSST features stay on the device
+    and feed the BiLSTM on PyTorch-ROCm; the expected log-probabilities were produced on the CPU by the REFERENCE
+    pipeline (reference FSST wrapper over the oracle core -> reference HeartSoundSegmenter,
+    /root/reference/hss/model/segmenter.py:20-87, main.py:170,221; tests/golden/make_golden.py segmenter_c4).
+    Tolerance: the features agree to ~1e-6 relative, MIOpen's fp32 LSTM reorders the 2 x 2000-step recurrences;
+    measured max |d log p| on MI355X is printed, gate 2e-3 absolute on log-probabilities (and 99.9 % of the
+    argmax decisions identical)."""
+    from heart_sounds_segmentation_amd.consumer import SegmenterHead, segment
+    g = np.load(os.path.join(GOLD, "segmenter_c4.npz"))
+    head = SegmenterHead.seeded_like_reference(int(g["seed"]))
+    assert head.checksum() == g["sha256"].tobytes(), "weight replay differs from the reference-made fixture"
+    head = head.cuda().eval()
+    X = synth.pcg_windows(50, 2000, seed=int(g["window_seed"]))
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    feats = tf.batch(torch.from_numpy(X).cuda())
+    assert np.abs(feats[:, ::250, :].cpu().numpy() - g["feat_probe"]).max() < 1e-4 * np.abs(g["feat_probe"]).max()
+    with torch.no_grad():
+        lp = segment(tf, head, torch.from_numpy(X).cuda()).cpu().numpy()
+    assert lp.shape == (50, 2000, 4)
+    d = np.abs(lp - g["y"])
+    agree = float((lp.argmax(-1) == g["y"].argmax(-1)).mean())
+    print(f"C4: max |d log p| = {d.max():.3e}, mean = {d.mean():.3e}, argmax agreement = {agree:.6f}")
+    assert d.max() < 2e-3 and agree > 0.999
+
+
 @pytest.mark.parametrize("band", [(25, 190), (0, 250), (400, 500), (7.8125, 7.8125), (490, 500), (0, 7)])
 def test_band_shapes_nwin128(oracle_mod, band):
     """Odd K, K > 24, bands touching DC / Nyquist, single-row bands: every epilogue variant of the

@@ -108,6 +108,26 @@ def test_consumer_matches_reference_segmenter_golden():
     assert np.abs(y.numpy() - g["y"]).max() < 1e-5
 
 
+def test_consumer_c4_size_matches_reference_pipeline(oracle_mod):
+    """BASELINE config C4 at its real size on the CPU: tests/golden/segmenter_c4.npz holds the output of the
+    reference's own pipeline (reference FSST wrapper over the oracle core -> HeartSoundSegmenter(44, batch 50,
+    hidden 240), hss/model/segmenter.py:20-87, main.py:170,221).  The weights are replayed from the seed (checksum
+    pinned); the features come from the oracle's C epilogue."""
+    import os
+    from heart_sounds_segmentation_amd import synth
+    from heart_sounds_segmentation_amd.consumer import SegmenterHead
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "segmenter_c4.npz"))
+    head = SegmenterHead.seeded_like_reference(int(g["seed"])).eval()
+    assert head.checksum() == g["sha256"].tobytes(), "weight replay differs from the reference-made fixture"
+    X = synth.pcg_windows(50, 2000, seed=int(g["window_seed"]))
+    feats = oracle_mod.features(X, 1000, synth.kaiser_window(128, 0.5), (25, 200), "stack", nthreads=8)
+    assert np.abs(feats[:, ::250, :] - g["feat_probe"]).max() < 5e-6          # the reference wrapper's features
+    with torch.no_grad():
+        y = head(torch.from_numpy(feats))
+    assert y.shape == (50, 2000, 4)
+    assert np.abs(y.numpy() - g["y"]).max() < 2e-4                              # log-probabilities, absolute
+
+
 def test_csv_ingest_matches_pandas(built_lib, tmp_path):
     """ingest.load_file == the reference's _load_file recipe (heart_sounds.py:193-197) on a synthetic
     file of the corpus format."""
