@@ -74,6 +74,10 @@ def lib():
         L.hssfsst_exec_frames.restype = c_int
         L.hssfsst_normalize_running.argtypes = [vp, vp, c_i64, c_int, vp, vp]
         L.hssfsst_normalize_running.restype = c_int
+        L.hssfsst_plan_last_exec_fused.argtypes = [vp]
+        L.hssfsst_plan_last_exec_fused.restype = c_int
+        L.hssfsst_plan_check.argtypes = [vp]
+        L.hssfsst_plan_check.restype = c_int
         L.hssfsst_plan_set_timing.argtypes = [vp, c_int]
         L.hssfsst_plan_set_timing.restype = c_int
         L.hssfsst_plan_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ip]

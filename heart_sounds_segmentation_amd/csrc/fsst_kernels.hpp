@@ -39,7 +39,7 @@ constexpr int kModeRaw = 0, kModeAbs = 1, kModeStack = 2, kModeStackUnnorm = 3;
 struct CoreParams {
     const float* x;       // [batch][n]
     float* out;           // per mode, see include/hssfsst.h
-    double* partials;     // [batch][nblk][4] = {sum re, sum re^2, sum im, sum im^2} (STACK only)
+    float* partials;      // [batch][nblk][kPartFloats] pivoted sums per 64-frame tile (STACK only; see "Statistics")
     const float* ctab;    // class-folded window tables, [(R/2+1) classes][32 n][4R]
     int n;                // samples per signal
     int klo;              // first kept row
@@ -266,6 +266,113 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Statistics of the STACK epilogue (FSST._stack_real_imag, synchrosqueeze.py:78-85: mean and UNBIASED std of
+// the real block and of the imag block over all K*n elements, torch.std semantics).
+//
+// Every core kernel emits one PARTIAL per piece of a signal (a 16-frame group of the MFMA kernel, a 64-frame tile
+// of the generic kernel): 8 floats {S1re, S2re, S1im, S2im, p_re, p_im, -, -} with S1 = sum (v - p), S2 = sum (v - p)^2
+// over the piece's valid cells and the pivot p = one cell of the piece itself.  Shifting by a value of the data keeps
+// the FLOAT32 sums small against the spread (a plain float32 sum x^2 loses the variance when mean^2 >> variance,
+// e.g. a DC-offset recording with a band that contains row 0).  From there on everything is float64: a piece's
+// moments about zero  sum x = n p + S1,  sum x^2 = S2 + p (2 S1 + n p)  are exact to 1e-16 and are simply added up
+// -- in a FIXED order: blocks of 16 consecutive pieces sequentially, then lane (block % 16) over blocks c, c + 16, ...,
+// then a butterfly over the 16 block lanes -- so the statistics are run-to-run deterministic, independent of which
+// wave produced which partial, and identical whether the sums are formed here (two-kernel path) or inside the fused
+// kernel of fsst_mfma128.hpp, whose teams add their pieces in exactly this order.  The float64 cancellation in
+// sum x^2 - (sum x)^2 / N is harmless whenever the float32 features themselves still resolve the spread.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPartFloats = 8;
+constexpr int kStatBlock = 16;             // pieces per block of the summation order
+
+// quantity q of a piece: 0 = sum re, 1 = sum re^2, 2 = sum im, 3 = sum im^2 (s1, s2, pivot of that block of columns)
+__device__ __forceinline__ double piece_moment(int q, double s1, double s2, double piv, double cnt)
+{
+    // explicit fma: the two call sites (stats kernel, fused kernel) must round identically whatever the compiler's
+    // contraction choices are
+    return (q & 1) ? fma(piv, fma(cnt, piv, 2.0 * s1), s2) : fma(cnt, piv, s1);
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
+
+// One full wave.  block_sum(blk, q) = sum of quantity q over the pieces of block blk (in piece order), called by lane
+// (blk % 16, q) for blk = lane >> 2, (lane >> 2) + 16, ...  total = number of elements per block of columns (K * ncols).
+// Returns {mean_re, 1/std_re, mean_im, 1/std_im} (float32, like the reference's float32 tensors; a zero variance gives
+// 1/0 = inf and the z-score (v - mean) * inf = NaN for every element, as torch's 0/0).
+template <class BlockSum>
+__device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 3;
+    double acc = 0.0;
+    for (int blk = lane >> 2; blk < nblocks; blk += 16) acc += block_sum(blk, q);
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+        const double o = shfl_xor_f64(acc, off);
+        acc = (lane & off) ? (o + acc) : (acc + o);      // lower lane's value is always the left operand
+    }
+    const double sx_re = __shfl(acc, 0, 64), sxx_re = __shfl(acc, 1, 64), sx_im = __shfl(acc, 2, 64), sxx_im = __shfl(acc, 3, 64);
+    const double mr = sx_re / total, mi = sx_im / total;
+    const double vr = fma(-sx_re, mr, sxx_re) / (total - 1.0), vi = fma(-sx_im, mi, sxx_im) / (total - 1.0);
+    return make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
+                       static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
+}
+
+// The two-kernel path: partials in HBM, [nparts][kPartFloats]; fpp = frames per piece.
+__device__ __forceinline__ float4 signal_stats(const float* part, int nparts, int fpp, int ncols, int K)
+{
+    const int nblocks = (nparts + kStatBlock - 1) / kStatBlock;
+    return stats_from_blocks(nblocks, static_cast<double>(K) * static_cast<double>(ncols), [&](int blk, int q) {
+        double s = 0.0;
+        const int g1 = min(nparts, (blk + 1) * kStatBlock);
+        for (int g = blk * kStatBlock; g < g1; ++g) {
+            const float* pp = part + static_cast<long long>(g) * kPartFloats;
+            const double cnt = static_cast<double>(min(fpp, ncols - fpp * g)) * static_cast<double>(K);
+            const int h = q >> 1;                        // 0 = real block, 1 = imaginary block
+            s += piece_moment(q, static_cast<double>(pp[2 * h]), static_cast<double>(pp[2 * h + 1]),
+                              static_cast<double>(pp[4 + h]), cnt);
+        }
+        return s;
+    });
+}
+
+// Wave-wide sums of the four per-lane accumulators of a piece in 10 instructions: two half swaps (v_permlane32_swap)
+// put the re pair in lanes 0-31 and the im pair in lanes 32-63, a row swap (v_permlane16_swap) gives each of the
+// four 16-lane rows one quantity, four DPP rotations finish inside the rows.  Result: every lane of row 0 / 1 / 2 / 3
+// holds S1re / S2re / S1im / S2im.  Fixed order => deterministic.
+__device__ __forceinline__ float piece_sums(float s_re, float q_re, float s_im, float q_im)
+{
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s_re), __float_as_uint(s_im), false, false);
+    const float u = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q_re), __float_as_uint(q_im), false, false);
+    const float v = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+    const auto r3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(v), false, false);
+    float w = __uint_as_float(r3[0]) + __uint_as_float(r3[1]);
+    w += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w), 0x128, 0xf, 0xf, false));   // row_ror:8
+    w += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w), 0x124, 0xf, 0xf, false));   // row_ror:4
+    w += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w), 0x122, 0xf, 0xf, false));   // row_ror:2
+    w += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return w;
+}
+
+// Stores a piece's partial: `w` from piece_sums (rows 0..3), pivot (p_re, p_im) in every lane.
+__device__ __forceinline__ void store_partial(float* part, float w, float p_re, float p_im)
+{
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0) part[lane >> 4] = w;
+    if (lane < 2) part[4 + lane] = lane ? p_im : p_re;
+}
+
+// Per-signal statistics from the partials: one wave per signal.
+// stats[b] = {mean_re, 1/std_re, mean_im, 1/std_im}.
+__global__ __launch_bounds__(64) void fsst_stats_kernel(const float* partials, float4* stats, int nparts, int fpp,
+                                                        int n, int K)
+{
+    const long long b = blockIdx.x;
+    const float4 st = signal_stats(partials + b * nparts * kPartFloats, nparts, fpp, n, K);
+    if (threadIdx.x == 0) stats[b] = st;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Core kernel: one block = one TILE-sample stretch of one signal; one lane = one hop-1 frame.
 // LDS: xs[TILE + nwin - 1 (+pad)] | own[2K][TILE + 1] | disp[2K][TILE + 1]; red[] aliases xs.
 // p.oneplane != 0: own and disp are the same plane (half the LDS; every own-row value then costs a read-modify-write
@@ -337,6 +444,9 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const int total = valid * C;
     int tt = tid / C, c = tid - tt * C;
     const int dtt = TILE / C, dc = TILE - dtt * C;
+    static_assert(TILE == 64, "one wave per tile: the statistics partial is a single-wave reduction");
+    // pivots of this tile's statistics partial: its first frame's first kept row (a value of the data itself)
+    const float p_re = acc[0], p_im = acc[K * LD];
     float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
     for (int e = tid; e < total; e += TILE) {
         float val;
@@ -345,60 +455,17 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
             val = sqrtf(fmaf(re, re, im * im));
         } else {
             val = acc[c * LD + tt];
-            if (c < K) { s_re += val; q_re = fmaf(val, val, q_re); }
-            else       { s_im += val; q_im = fmaf(val, val, q_im); }
+            if (c < K) { const float d = val - p_re; s_re += d; q_re = fmaf(d, d, q_re); }
+            else       { const float d = val - p_im; s_im += d; q_im = fmaf(d, d, q_im); }
         }
         dst[e] = val;
         c += dc; tt += dtt;
         if (c >= C) { c -= C; ++tt; }
     }
     if (p.mode != kModeStack) return;
-
-    // per-tile statistics partials in fp64 (fixed reduction order => run-to-run deterministic)
-    double v0 = wave_sum(static_cast<double>(s_re)), v1 = wave_sum(static_cast<double>(q_re));
-    double v2 = wave_sum(static_cast<double>(s_im)), v3 = wave_sum(static_cast<double>(q_im));
-    double* part = p.partials + (b * p.nblk + blk) * 4;
-    if constexpr (TILE == 64) {
-        if (tid == 0) { part[0] = v0; part[1] = v1; part[2] = v2; part[3] = v3; }
-    } else {
-        __syncthreads();                                  // everyone is done reading acc/xs
-        double* red = reinterpret_cast<double*>(smem);    // XS >= 4*(TILE/64) doubles always holds
-        const int wv = tid >> 6;
-        if ((tid & 63) == 0) { red[wv * 4 + 0] = v0; red[wv * 4 + 1] = v1; red[wv * 4 + 2] = v2; red[wv * 4 + 3] = v3; }
-        __syncthreads();
-        if (tid < 4) {
-            double s = 0.0;
-            for (int w2 = 0; w2 < TILE / 64; ++w2) s += red[w2 * 4 + tid];
-            part[tid] = s;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// STACK epilogue, second half of FSST._stack_real_imag (synchrosqueeze.py:78-85): per signal mean
-// and UNBIASED std of the real block and of the imag block over all K*n elements, then
-// (v - mean) / std in float32, in place (evaluated as (v - mean) * (1/std): <= 1.5 ulp from the
-// reference's division).  Pure streaming, in place: linear float4 grid-stride sweep per signal.
-// grid = (chunks, batch), block = 256.
-// ------------------------------------------------------------------------------------------------
-// Per-signal statistics from the per-tile fp64 partials: one wave per signal, fixed reduction order.
-// stats[b] = {mean_re, 1/std_re, mean_im, 1/std_im} (float32, as the reference's float32 tensors).
-__global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, float4* stats, int nblk,
-                                                        int n, int K)
-{
-    const long long b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double* part = partials + b * nblk * 4;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int i = lane; i < nblk; i += 64) { a0 += part[i * 4]; a1 += part[i * 4 + 1]; a2 += part[i * 4 + 2]; a3 += part[i * 4 + 3]; }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    if (lane == 0) {
-        const double cnt = static_cast<double>(K) * static_cast<double>(n);
-        const double mr = a0 / cnt, mi = a2 / cnt;
-        const double vr = (a1 - a0 * mr) / (cnt - 1.0), vi = (a3 - a2 * mi) / (cnt - 1.0);
-        stats[b] = make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
-                               static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
-    }
+    // per-tile statistics partial (fixed reduction order => run-to-run deterministic)
+    const float w = piece_sums(s_re, q_re, s_im, q_im);
+    store_partial(p.partials + (b * p.nblk + blk) * kPartFloats, w, p_re, p_im);
 }
 
 // grid = any number of blocks of 256 (the host sizes it to a fraction of the chip so the sweep can
@@ -407,8 +474,8 @@ __global__ __launch_bounds__(64) void fsst_stats_kernel(const double* partials, 
 // fsst_stats_kernel, same order, same result) instead of reading `stats`: one launch less per transform.
 // `slices` > 1 cuts every signal into that many contiguous pieces, one block each (small batches: a block per
 // signal would leave most of the chip idle); the fused reduction is only used with slices == 1.
-__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, const double* partials,
-                                                             int nblk, int n, int K, int nsignals, int slices)
+__global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, const float* partials,
+                                                             int nblk, int fpp, int n, int K, int nsignals, int slices)
 {
     __shared__ float4 st_sh;
     const int tid = threadIdx.x;
@@ -419,17 +486,8 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
         float4 st;
         if (partials != nullptr) {
             if (tid < 64) {
-                const double* part = partials + static_cast<long long>(sig) * nblk * 4;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                for (int i = tid; i < nblk; i += 64) { a0 += part[i * 4]; a1 += part[i * 4 + 1]; a2 += part[i * 4 + 2]; a3 += part[i * 4 + 3]; }
-                a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-                if (tid == 0) {
-                    const double cnt = static_cast<double>(K) * static_cast<double>(n);
-                    const double mr = a0 / cnt, mi = a2 / cnt;
-                    const double vr = (a1 - a0 * mr) / (cnt - 1.0), vi = (a3 - a2 * mi) / (cnt - 1.0);
-                    st_sh = make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
-                                        static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
-                }
+                const float4 r = signal_stats(partials + static_cast<long long>(sig) * nblk * kPartFloats, nblk, fpp, n, K);
+                if (tid == 0) st_sh = r;
             }
             __syncthreads();
             st = st_sh;

@@ -148,8 +148,12 @@ struct hssfsst_plan {
     float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
     int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
-    double* d_partials = nullptr; size_t partials_cap = 0;   // doubles
+    float* d_partials = nullptr;  size_t partials_cap = 0;   // floats (kPartFloats per statistics piece)
+    unsigned long long* d_ws = nullptr; size_t ws_cap = 0;   // fused z-score: statistics granules (8 bytes each)
+    unsigned* d_status = nullptr;                            // fused z-score: device status word (0 = ok)
+    int last_fused = 0;                                      // the last exec ran the fused z-score kernel
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
+    int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
@@ -226,10 +230,64 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     return 0;
 }
 
-int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* dout, double* partials, int n, int col0,
-                   int ncols, int64_t batch, hipStream_t st)
+int grow(void** ptr, size_t* cap, size_t need, size_t elem)
 {
-    hssfsst::Core128Params cp;
+    if (need <= *cap) return 0;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc(ptr, need * elem);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(HSSFSST_ENOMEM, "hipMalloc(%zu B): %s", need * elem, hipGetErrorString(e)); }
+    *cap = need;
+    return 0;
+}
+
+// Fused z-score launch (nwin = 128, STACK, wide-store epilogue; fsst_mfma128.hpp "Fused z-score").  Returns 1 when it
+// launched, 0 when this exec should take the two-pass path (signal too long for a team, batch too small to occupy the
+// teams, device smaller than expected), < 0 on error.
+template <int S1C>
+int launch_fused128(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    constexpr int WPB = 16, FPW = 16;
+    int team = 1;
+    while (WPB * team < ngroups) team *= 2;
+    if (team > 32) return 0;
+    const size_t lds = (hssfsst::core128_atab_floats(8, 16) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
+                        hssfsst::wave_lds_floats(FPW, pl->klo, pl->K, 8, 16)) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    auto kern = hssfsst::fsst_core128_kernel<16, 8, FPW, true, WPB, S1C, true>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->fused_slots == 0) {                          // every block must be resident: the teams wait for each other
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->fused_slots = (per_cu >= 1 && cus >= 1) ? cus : -1;       // one block per CU
+    }
+    if (pl->fused_slots < 8 * team) return 0;
+    const int grid = (pl->fused_slots / (8 * team)) * (8 * team);
+    const int nteams = grid / team;
+    if (batch < 2 * static_cast<int64_t>(nteams)) return 0;           // too few signals to keep the teams busy
+    if (batch / nteams + 2 >= (1ll << 31)) return 0;
+    const size_t nws = static_cast<size_t>(nteams) * hssfsst::kFusedSlots * team * 8;    // [teams][slots][CUs of the team][8 granules]
+    int rc;
+    if ((rc = grow(reinterpret_cast<void**>(&pl->d_ws), &pl->ws_cap, nws, sizeof(unsigned long long))) != 0) return rc;
+    if (!pl->d_status) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_status), sizeof(unsigned)));
+        HIP_TRY(hipMemset(pl->d_status, 0, sizeof(unsigned)));
+    }
+    // every polled word is zeroed before every launch (tags count the team's signals from 1 within a launch)
+    HIP_TRY(hipMemsetAsync(pl->d_ws, 0, nws * sizeof(unsigned long long), st));
+    cp.ws = pl->d_ws; cp.status = pl->d_status; cp.team = team;
+    static const int tune = std::getenv("HSSFSST_FUSED_TUNE") ? std::atoi(std::getenv("HSSFSST_FUSED_TUNE")) : 0;
+    cp.tune = tune;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
+    HIP_TRY(hipGetLastError());
+    return 1;
+}
+
+int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* dout, float* partials, int n, int col0,
+                   int ncols, int64_t batch, hipStream_t st, bool try_fused, bool* did_fuse)
+{
+    hssfsst::Core128Params cp{};
     cp.xstride = xstride;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = static_cast<int>(batch);
@@ -246,6 +304,13 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     // bands that start in stripe 0 of the own plane and end in stripe 3 (the canonical [25, 200] Hz at fs = 1000 for
     // nwin 128 and 256) get kernels with compile-time stripe tests
     const bool canon = hssfsst::own_s0(pl->klo, rq) == 0 && hssfsst::own_s1(pl->klo, pl->K, rq) == 3;
+    *did_fuse = false;
+    if (try_fused && fast && nt == 16 && rq == 8 && pl->mode == HSSFSST_MODE_STACK) {
+        const int ngroups = (ncols + 15) / 16;
+        const int rc = canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
+        if (rc < 0) return rc;
+        if (rc == 1) { *did_fuse = true; return 0; }
+    }
     if (nt == 16 && rq == 8) {
         if (fast && canon) return launch_core128_wpb<16, 8, true, 16, 3>(pl, cp, nchunks, st);
         if (fast) return launch_core128_wpb<16, 8, true, 16>(pl, cp, nchunks, st);   // K <= 24: 16 regions always fit
@@ -270,16 +335,6 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (fast && fixed + 2 * per_wave <= room) return launch_core128_wpb<32, 16, true, 2>(pl, cp, nchunks, st);
     }
     return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B per wave exceeds the 160 KiB budget", per_wave);
-}
-
-int grow(void** ptr, size_t* cap, size_t need, size_t elem)
-{
-    if (need <= *cap) return 0;
-    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
-    hipError_t e = hipMalloc(ptr, need * elem);
-    if (e != hipSuccess) { *ptr = nullptr; return fail(HSSFSST_ENOMEM, "hipMalloc(%zu B): %s", need * elem, hipGetErrorString(e)); }
-    *cap = need;
-    return 0;
 }
 
 }  // namespace
@@ -437,6 +492,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_ctab) (void)hipFree(p->d_ctab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
+    if (p->d_ws) (void)hipFree(p->d_ws);
+    if (p->d_status) (void)hipFree(p->d_status);
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
@@ -458,6 +515,26 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
     if (ofps) *ofps = out_floats_per_sample(p);
     if (mode) *mode = p->mode;
     if (device) *device = p->device;
+    return 0;
+}
+
+#ifdef HSS_FUSEPROBE
+void* hssfsst_debug_partials(hssfsst_plan* p) { return p ? p->d_partials : nullptr; }
+#endif
+
+int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? 1 : 0; }
+
+int hssfsst_plan_check(hssfsst_plan* p)
+{
+    if (!p) return fail(HSSFSST_EINVAL, "plan_check: plan is NULL");
+    if (!p->d_status) return 0;
+    DEVICE_SCOPE(p->device);
+    unsigned code = 0;
+    HIP_TRY(hipMemcpy(&code, p->d_status, sizeof(code), hipMemcpyDeviceToHost));   // waits for the device
+    if (code != 0) {
+        (void)hipMemset(p->d_status, 0, sizeof(code));
+        return fail(HSSFSST_EHIP, "fused z-score: a wait inside the kernel gave up (code %u); results of that exec are invalid", code);
+    }
     return 0;
 }
 
@@ -517,9 +594,9 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
     DEVICE_SCOPE(p->device);
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
-    // statistics partials per signal: one per chunk (nwin 128) / per 64-frame tile (generic kernel)
-    const int nblk = use128 ? hssfsst::core128_chunks_per_signal(hssfsst::core128_regions((ncols + 15) / 16))
-                            : (ncols + kTile - 1) / kTile;
+    // statistics partials per signal: one per 16-frame group (MFMA kernel) / per 64-frame tile (generic kernel)
+    const int fpp = use128 ? 16 : kTile;
+    const int nblk = (ncols + fpp - 1) / fpp;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
@@ -541,7 +618,7 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
     }
     if (p->mode == HSSFSST_MODE_STACK)
     {
-        if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * 4, sizeof(double))) != 0) return rc;
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_partials), &p->partials_cap, static_cast<size_t>(nblocks) * hssfsst::kPartFloats, sizeof(float))) != 0) return rc;
         if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
     }
 
@@ -589,13 +666,15 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         const float* cx = dx + c0 * x_stride;
         float* cout = dout + c0 * per;
         hssfsst::CoreParams cp;
-        cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * 4 : nullptr; cp.ctab = p->d_ctab;
+        cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * hssfsst::kPartFloats : nullptr; cp.ctab = p->d_ctab;
         cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols; cp.xstride = x_stride;
         const long long cblocks = static_cast<long long>(cb) * nblk;
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
+        bool did_fuse = false;
+        static const bool no_fused = std::getenv("HSSFSST_NO_FUSED") != nullptr;        // A/B and bit-equality tests
         if (use128) {
-            rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st);
+            rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st, !no_fused && !piped, &did_fuse);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
@@ -606,7 +685,8 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         }
         if (rc != 0) return rc;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
-        if (p->mode == HSSFSST_MODE_STACK) {
+        p->last_fused = did_fuse ? 1 : 0;
+        if (p->mode == HSSFSST_MODE_STACK && !did_fuse) {
             hipStream_t zs = st;
             if (piped) {
                 HIP_TRY(hipEventRecord(p->sync_ev[ci], st));
@@ -633,9 +713,9 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
             const bool fused = !split_stats && slices == 1 && zgrid == cb && cb >= 512;
             if (!fused)
                 hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, zs,
-                                   cp.partials, cstats, nblk, ncols, p->K);
+                                   cp.partials, cstats, nblk, fpp, ncols, p->K);
             hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, zs,
-                               cout, cstats, fused ? cp.partials : nullptr, nblk, ncols, p->K, static_cast<int>(cb), slices);
+                               cout, cstats, fused ? cp.partials : nullptr, nblk, fpp, ncols, p->K, static_cast<int>(cb), slices);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -652,6 +732,7 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;
     } else if (!x_on_device) {
         HIP_TRY(hipStreamSynchronize(st));   // the host source may be reused by the caller
     }
@@ -725,7 +806,7 @@ int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int 
                        state, stats, static_cast<int>(batch));
     const int64_t zgrid = batch < 4096 ? batch : 4096;
     hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, st,
-                       feats, stats, static_cast<const double*>(nullptr), 0, n, p->K, static_cast<int>(batch), 1);
+                       feats, stats, static_cast<const float*>(nullptr), 0, 0, n, p->K, static_cast<int>(batch), 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }

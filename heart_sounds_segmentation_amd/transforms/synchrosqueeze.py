@@ -213,6 +213,14 @@ class FSST:
             raise ValueError(f"FSST.batch: expected (B, n), got {tuple(X.shape)}")
         return self._run(X, out=out)
 
+    def check(self, device_index: Optional[int] = None) -> bool:
+        """Extension: waits for the device and raises ``RuntimeError`` if a kernel reported a failed internal wait;
+        returns True when the plan's last ``stack`` call ran the fused (single-pass) kernel."""
+        dev = self._device_index() if device_index is None else device_index
+        plan = self._plan(dev)
+        _lib.check(_lib.lib().hssfsst_plan_check(plan.handle), "hssfsst_plan_check")
+        return bool(_lib.lib().hssfsst_plan_last_exec_fused(plan.handle))
+
     def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
         """Extension (bench): record HIP events around the kernels of every following call."""
         dev = self._device_index() if device_index is None else device_index

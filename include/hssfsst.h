@@ -86,6 +86,16 @@ int hssfsst_exec_cols(hssfsst_plan* plan, const float* x, int64_t batch, int n, 
 int hssfsst_exec_frames(hssfsst_plan* plan, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
                         int x_on_device, float* out, int out_on_device, void* stream);
 
+/* Device-side health of the plan's asynchronous work: waits for the device, then returns HSSFSST_EHIP if a bounded
+ * wait inside a kernel gave up since the last check (never expected: it would mean the GPU did not keep the kernel's
+ * blocks co-resident).  Host-output execs call it themselves; callers of device-output execs may call it after
+ * synchronising. */
+int hssfsst_plan_check(hssfsst_plan* plan);
+
+/* 1 when the plan's last STACK exec ran the fused core + z-score kernel (one pass over HBM), 0 when it took the
+ * two-kernel path (short batches, long signals, other window lengths).  Both give bit-identical results. */
+int hssfsst_plan_last_exec_fused(const hssfsst_plan* plan);
+
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
  * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the

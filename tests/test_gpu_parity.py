@@ -468,7 +468,7 @@ def test_c4_end_to_end_matches_reference_pipeline():
     pipeline (reference FSST wrapper over the oracle core -> reference HeartSoundSegmenter,
     /root/reference/hss/model/segmenter.py:20-87, main.py:170,221; tests/golden/make_golden.py segmenter_c4).
     Tolerance: the features agree to ~1e-6 relative, MIOpen's fp32 LSTM reorders the 2 x 2000-step recurrences;
-    measured max |d log p| on MI355X is printed, gate 2e-3 absolute on log-probabilities (and 99.9 % of the
+    measured max |d log p| on MI355X is printed, gate 2e-5 absolute on log-probabilities (measured 3.6e-7; and all of the
     argmax decisions identical)."""
     from heart_sounds_segmentation_amd.consumer import SegmenterHead, segment
     g = np.load(os.path.join(GOLD, "segmenter_c4.npz"))
@@ -485,7 +485,7 @@ def test_c4_end_to_end_matches_reference_pipeline():
     d = np.abs(lp - g["y"])
     agree = float((lp.argmax(-1) == g["y"].argmax(-1)).mean())
     print(f"C4: max |d log p| = {d.max():.3e}, mean = {d.mean():.3e}, argmax agreement = {agree:.6f}")
-    assert d.max() < 2e-3 and agree > 0.999
+    assert d.max() < 2e-5 and agree == 1.0
 
 
 @pytest.mark.parametrize("band", [(25, 190), (0, 250), (400, 500), (7.8125, 7.8125), (490, 500), (0, 7)])
