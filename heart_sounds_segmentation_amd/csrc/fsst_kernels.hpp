@@ -292,25 +292,39 @@ __device__ __forceinline__ double piece_moment(int q, double s1, double s2, doub
     return (q & 1) ? fma(piv, fma(cnt, piv, 2.0 * s1), s2) : fma(cnt, piv, s1);
 }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
+// (lane passed in: callers inside a register-starved loop hand over an opaque copy so that nothing derived from it is
+// hoisted out of their loop)
+__device__ __forceinline__ double shfl_xor_f64(double v, int off, int lane)
+{
+    const int src = (lane ^ off) << 2;
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src, static_cast<int>(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
 
 // One full wave.  block_sum(blk, q) = sum of quantity q over the pieces of block blk (in piece order), called by lane
 // (blk % 16, q) for blk = lane >> 2, (lane >> 2) + 16, ...  total = number of elements per block of columns (K * ncols).
 // Returns {mean_re, 1/std_re, mean_im, 1/std_im} (float32, like the reference's float32 tensors; a zero variance gives
 // 1/0 = inf and the z-score (v - mean) * inf = NaN for every element, as torch's 0/0).
 template <class BlockSum>
-__device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum)
+__device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum, int lane)
 {
-    const int lane = threadIdx.x & 63;
     const int q = lane & 3;
     double acc = 0.0;
     for (int blk = lane >> 2; blk < nblocks; blk += 16) acc += block_sum(blk, q);
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) {
-        const double o = shfl_xor_f64(acc, off);
+        const double o = shfl_xor_f64(acc, off, lane);
         acc = (lane & off) ? (o + acc) : (acc + o);      // lower lane's value is always the left operand
     }
-    const double sx_re = __shfl(acc, 0, 64), sxx_re = __shfl(acc, 1, 64), sx_im = __shfl(acc, 2, 64), sxx_im = __shfl(acc, 3, 64);
+    auto from_lane = [&](int l) {
+        const long long b = __double_as_longlong(acc);
+        const int lo = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffll), l);
+        const int hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), l);
+        return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+    };
+    const double sx_re = from_lane(0), sxx_re = from_lane(1), sx_im = from_lane(2), sxx_im = from_lane(3);
     const double mr = sx_re / total, mi = sx_im / total;
     const double vr = fma(-sx_re, mr, sxx_re) / (total - 1.0), vi = fma(-sx_im, mi, sxx_im) / (total - 1.0);
     return make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
@@ -318,7 +332,7 @@ __device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, B
 }
 
 // The two-kernel path: partials in HBM, [nparts][kPartFloats]; fpp = frames per piece.
-__device__ __forceinline__ float4 signal_stats(const float* part, int nparts, int fpp, int ncols, int K)
+__device__ __forceinline__ float4 signal_stats(const float* part, int nparts, int fpp, int ncols, int K, int lane)
 {
     const int nblocks = (nparts + kStatBlock - 1) / kStatBlock;
     return stats_from_blocks(nblocks, static_cast<double>(K) * static_cast<double>(ncols), [&](int blk, int q) {
@@ -332,7 +346,7 @@ __device__ __forceinline__ float4 signal_stats(const float* part, int nparts, in
                               static_cast<double>(pp[4 + h]), cnt);
         }
         return s;
-    });
+    }, lane);
 }
 
 // Wave-wide sums of the four per-lane accumulators of a piece in 10 instructions: two half swaps (v_permlane32_swap)
@@ -357,9 +371,11 @@ __device__ __forceinline__ float piece_sums(float s_re, float q_re, float s_im, 
 // Stores a piece's partial: `w` from piece_sums (rows 0..3), pivot (p_re, p_im) in every lane.
 __device__ __forceinline__ void store_partial(float* part, float w, float p_re, float p_im)
 {
+    // no predicates (each costs a v_cmp + exec save / restore): the 16 lanes of a row store the same value to the same
+    // word, even / odd lanes the two pivots
     const int lane = threadIdx.x & 63;
-    if ((lane & 15) == 0) part[lane >> 4] = w;
-    if (lane < 2) part[4 + lane] = lane ? p_im : p_re;
+    part[lane >> 4] = w;
+    part[4 + (lane & 1)] = (lane & 1) ? p_im : p_re;
 }
 
 // Per-signal statistics from the partials: one wave per signal.
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(64) void fsst_stats_kernel(const float* partials, f
                                                         int n, int K)
 {
     const long long b = blockIdx.x;
-    const float4 st = signal_stats(partials + b * nparts * kPartFloats, nparts, fpp, n, K);
+    const float4 st = signal_stats(partials + b * nparts * kPartFloats, nparts, fpp, n, K, threadIdx.x & 63);
     if (threadIdx.x == 0) stats[b] = st;
 }
 
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
         float4 st;
         if (partials != nullptr) {
             if (tid < 64) {
-                const float4 r = signal_stats(partials + static_cast<long long>(sig) * nblk * kPartFloats, nblk, fpp, n, K);
+                const float4 r = signal_stats(partials + static_cast<long long>(sig) * nblk * kPartFloats, nblk, fpp, n, K, tid);
                 if (tid == 0) st_sh = r;
             }
             __syncthreads();

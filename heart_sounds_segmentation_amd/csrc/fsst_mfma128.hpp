@@ -72,11 +72,7 @@ struct Core128Params {
     int ncols;            // number of output columns (== n for a whole-signal transform)
     long long xstride;    // samples between the starts of consecutive signals (n for a dense batch)
     Core128Regions reg;
-    // FUSED kernel only (z-score inside the core launch, see "Fused z-score" below)
-    unsigned long long* ws;   // statistics granules [teams][3][waves per team][6], 8-byte {tag, value}, zeroed per launch
-    unsigned* status;         // device status word: 0 = ok, else the code of a spin that gave up
-    int team;                 // CUs per team
-    int tune;                 // development: scheduling variant (HSSFSST_FUSED_TUNE)
+    unsigned* status;         // FUSED kernel only: device status word, 0 = ok, else the code of a wait that gave up
 };
 
 // Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
@@ -221,12 +217,14 @@ __host__ __device__ constexpr int own_ld(int klo, int K, int rq = 8)
 // MFMA A-operand constants: [pass][nt taps][k-step][64 lanes] floats, rq / 8 passes of rq / 4 k-steps
 __host__ __device__ constexpr int core128_atab_floats(int rq = 8, int nt = 16) { return (rq / 8) * nt * (rq / 4) * 64; }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
-constexpr int kCtlFloats = 32 + 192 + 384 + 64;   // block control words in LDS: [0] chunk counter; FUSED: [1..3] resolver claims,
-                                             // [4..6] epochs of the resolved statistics, [7..9] arrival counters, [10] dead
-                                             // flag, [16..27] three float4 statistics, [32..223] the wide-store offset
-                                             // table (3 words per lane), [224..607] float64 moments [3][16 waves][4],
-                                             // [608..671] per-lane column classes of the z-score pass
-constexpr int kFusedSlots = 5;               // depth of the granule ring in HBM (see "Fused z-score")
+constexpr int kCtlFloats = 16;               // block control words in LDS: [0] work counter
+// FUSED kernel: [0] ticket counter, [1..2] groups delivered per signal slot (monotone), [3] a wait gave up, [4..7] epoch
+// of the resolved statistics (4 slots), [8..15] (unused), [16..79] per-lane column classes of the z-score
+// pass, [80..271] the wide-store offset table (3 words per lane; the fused kernel has no register to spare for it),
+// [272..287] four float4 statistics, [288 ..] the statistics partials of two signals [2][kFusedMaxGroups][kPartFloats]
+constexpr int kFusedMaxGroups = 128;         // signals of at most 2048 frames
+constexpr int kFusedMinChunks = 16;          // and of at least 16 chunks: see "Slots" in the kernel
+constexpr int kCtlFusedFloats = 288 + 2 * kFusedMaxGroups * kPartFloats;
 
 // FAST epilogue: byte offsets, inside a wave's own plane, of the two (re,re) / (im,im) pairs that make up
 // float4 number f = lane + 64 i of a 16-frame group's contiguous [16][2K] output image (K even, K <= 24).
@@ -335,9 +333,8 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
 // [25, 200] Hz at fs = 1000 is stripes 0..3 for every RQ); the per-source "does this stripe have a column in the own
 // plane" tests and their branches are then compile-time (measured 3.3-3.6 % of the kernel; making the whole band
 // (klo, K) a compile-time constant gave nothing more).  S1C = -1: any band.
-// FUSED (z-score inside the core launch; STACK, FAST epilogue, signals of at most WPB * team groups): see the section
-// "Fused z-score" after this kernel's work loop.
-using gu64 = __attribute__((address_space(1))) unsigned long long;
+// FUSED (z-score inside the core launch; STACK, FAST epilogue, signals of at most kFusedMaxGroups groups): see the section
+// "Fused z-score" inside the kernel.
 using gu32 = __attribute__((address_space(1))) unsigned;
 constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives up (a poll takes ~0.1 us: ~30 ms; a healthy
                                                    // wait is microseconds).  After the first give-up of a block its other
@@ -346,9 +343,10 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
 template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false>
 __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_core128_kernel(Core128Params p)
 {
-    static_assert(!FUSED || (FAST && FPW == 16), "the fused z-score rides on the wide-store epilogue, one group per tile");
+    static_assert(!FUSED || FAST, "the fused z-score rides on the wide-store epilogue");
     constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
     constexpr int ATAB = core128_atab_floats(RQ, NT);
+    constexpr int CTL = FUSED ? kCtlFusedFloats : kCtlFloats;
     constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
     using avec = float __attribute__((ext_vector_type(KST)));          // one tap's A operand, all k-steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -364,16 +362,15 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
     float* atab = smem;                                                      // [pass][NT taps][64 lanes][KST]
-    int* next_q = reinterpret_cast<int*>(smem + ATAB);                       // block's chunk counter
-    unsigned* claim = reinterpret_cast<unsigned*>(smem + ATAB) + 1;          // FUSED: [3] epoch a resolver took
-    unsigned* fin_epoch = claim + 3;                                         // FUSED: [3] epoch of fin_stats[]
-    unsigned* cu_cnt = fin_epoch + 3;                                        // FUSED: [3] waves of this CU that delivered
-    unsigned* dead = cu_cnt + 3;                                             // FUSED: a wait of this block gave up
-    unsigned* cu_done = dead + 1;                                            // FUSED: iterations all waves of this CU finished
-    float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + 16);         // FUSED: [3] resolved statistics
-    double* cu_part = reinterpret_cast<double*>(smem + ATAB + 224);          // FUSED: [3][WPB][4] moments of the waves' pieces
-    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 608);      // FUSED: [64] see "cls" in B below
-    float* wbase = smem + ATAB + kCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
+    int* next_q = reinterpret_cast<int*>(smem + ATAB);                       // block's work counter
+    unsigned* done_a = reinterpret_cast<unsigned*>(smem + ATAB) + 1;         // FUSED: [2] groups delivered (monotone)
+    unsigned* dead = done_a + 2;                                             // FUSED: a wait of this block gave up
+    unsigned* ready = dead + 1;                                              // FUSED: [4] epoch of fin_stats[]
+    float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + 272);        // FUSED: [4] resolved statistics
+    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // FUSED: [64] see "cls" below
+    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // FUSED: [3][64] wide-store offsets
+    float* part_lds = smem + ATAB + 288;                                     // FUSED: [2][kFusedMaxGroups][kPartFloats]
+    float* wbase = smem + ATAB + CTL + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
@@ -388,7 +385,25 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane == 0) *flag = 0;
-    if (threadIdx.x < 12) next_q[threadIdx.x] = 0;        // chunk counter, claims, epochs, arrival counters, dead flag, done
+    if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
+    if constexpr (FUSED) {
+        if (wv == 0) {
+            // bit 2i / 2i+1 of cls: the first / second pair of this lane's float4 i (of a group's [16][2K] image) is an
+            // imaginary column
+            unsigned cls = 0u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned c = (4u * static_cast<unsigned>(lane + 64 * i)) % static_cast<unsigned>(2 * K);
+                cls |= (c >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i);
+                cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
+            }
+            cls_lds[lane] = cls;
+            const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                ppk_lds[i * 64 + lane] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
+        }
+    }
     __syncthreads();
 
     // chunk bookkeeping (wave-uniform)
@@ -396,93 +411,87 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const int nc1 = nc0 + p.nsig * p.reg.npc[1];
     const int nchunks = nc1 + p.nsig * p.reg.npc[2];
     const int ngroups = (ncols + 15) >> 4;
-    auto draw = [&]() -> int {                           // next chunk of this block, or nchunks when it has none left
+    // FUSED work list of this block (wave-uniform): signals blockIdx, blockIdx + grid, ... (nk of them), each cut into
+    // NC chunks of FPW / 16 groups; see "Fused z-score" below for the order of the 2 NC nk tickets
+    constexpr int GPCF = FPW / 16;
+    const int nk = (FUSED && p.nsig > static_cast<int>(blockIdx.x)) ? (p.nsig - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : 0;
+    const int NC = (ngroups + GPCF - 1) / GPCF;
+    const int lead = min(8, NC);
+    const int nwork = FUSED ? 2 * NC * nk : nchunks;
+    auto draw = [&]() -> int {                           // next work item of this block, or nwork when none is left
         int q = 0;
         if (lane == 0) q = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         q = __builtin_amdgcn_readfirstlane(q);
+        if constexpr (FUSED) return q < nwork ? q : nwork;
         const long long c = static_cast<long long>(blockIdx.x) + static_cast<long long>(q) * gridDim.x;
-        return c < nchunks ? static_cast<int>(c) : nchunks;
+        return c < nwork ? static_cast<int>(c) : nwork;
     };
-    // FUSED work distribution (wave-uniform): block -> (XCD, slot) -> team of p.team CUs that share one L2
-    // (blockIdx % 8 is the XCD on this chip: used for locality only, never for correctness)
-    const int tsize = FUSED ? p.team : 1;
-    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
-    const int team = (bslot / tsize) * 8 + xcd, nteams = ((gridDim.x >> 3) / tsize) * 8;
-    const int wpt = WPB * tsize;                          // waves per team = groups of a signal in flight
-    const int tw = (bslot % tsize) * WPB + wv;            // this wave's index in its team = its group of every signal
-    const int nk = (FUSED && p.nsig > team) ? (p.nsig - team + nteams - 1) / nteams : 0;
-    int it = 0;                                           // FUSED: iteration = index of the team's signal being computed
-    float nx[3] = {0.0f, 0.0f, 0.0f};                     // FUSED: next signal's tile, in flight across the z-score phase
-    int chunk = FUSED ? 0 : draw();
-    f2* row_disp = disp_base + j * LDF;
+    int chunk = draw();
     const float* myA = atab + lane * KST;
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
     // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
     // this lane's six LDS byte offsets of the store pass (host-made table, core128_store_offsets), two 16-bit
     // offsets per register: three VGPRs for the whole kernel (six pushed the register allocation into scratch)
-    // (the fused kernel has no register to spare for them and re-reads them from LDS in every group)
     unsigned ppk[3] = {0u, 0u, 0u};
-    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 32);
-    if constexpr (FAST) {
+    if constexpr (FAST && !FUSED) {
         const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             ppk[i] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
-        if constexpr (FUSED) {
-            if (wv == 0) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) ppk_lds[i * 64 + lane] = ppk[i];
-                // bit 2i / 2i+1 of cls: the first / second pair of this lane's float4 i (of a group's [16][2K] image) is
-                // an imaginary column
-                unsigned cls = 0u;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const unsigned c = (4u * static_cast<unsigned>(lane + 64 * i)) % static_cast<unsigned>(2 * K);
-                    cls |= (c >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i);
-                    cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
-                }
-                cls_lds[lane] = cls;
-            }
-            __syncthreads();
-        }
     }
-#ifdef HSS_FUSEPROBE
-    unsigned long long pr_t = __builtin_readcyclecounter(), pr_acc[6] = {0, 0, 0, 0, 0, 0};
-#define PR_MARK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pr_acc[i] += t_ - pr_t; pr_t = t_; }
-#else
-#define PR_MARK(i)
-#endif
-    const int depth = (FUSED && (p.tune & 16)) ? 1 : 2;   // iterations between a group's computation and its z-score
-    while (FUSED ? (it <= nk + depth - 1) : (chunk < nchunks)) {
+    while (chunk < nwork) {
     // decode: signal, first group, number of groups
     long long b;
     int grp0, ngrp;
+    long long ksig = 0;                                  // FUSED: index of the signal in this block's list
+    bool zpass = false;                                  // FUSED: this ticket is a z-score chunk
     if constexpr (FUSED) {
-        // Issue priority by lag.  The SIMD arbiter favours the oldest wave; with a dependency between the waves of a
-        // CU (nobody gets the statistics of a signal before the slowest wave delivered its piece) that turns into a
-        // convoy: the old waves run two iterations ahead and block, the young ones then run alone, one wave per SIMD,
-        // at single-wave issue efficiency (measured: 54 % issue utilisation, 9.3 us per iteration instead of 4.7).
-        // A wave that is level with the slowest wave of its CU takes priority 3, one iteration ahead 1, further 0.
-        {
-            unsigned done = 0;
-            if (lane == 0) done = __hip_atomic_load(cu_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int lag = it - static_cast<int>(__builtin_amdgcn_readfirstlane(done));
-            if ((p.tune & 15) == 0) {
-                if (lag <= 0) __builtin_amdgcn_s_setprio(3);
-                else if (lag == 1) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            } else if ((p.tune & 15) == 1) {
-                if (lag <= 1) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(0);
-            } else if ((p.tune & 15) == 2) {
-                if (lag <= 0) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(0);
-            }
+        // ------------------------------------------------------------------------------------------------
+        // Fused z-score (FSST._stack_real_imag, synchrosqueeze.py:78-85) inside the core launch.
+        // One CU owns whole signals; nothing crosses CUs (no flags in HBM, no placement assumption, no way to hang on
+        // another block).  Its 16 waves draw TICKETS from one LDS counter.  A ticket is either a transform chunk A(k, c)
+        // -- FPW / 16 groups of the block's k-th signal: transform, un-normalised features to HBM with ordinary stores,
+        // one statistics partial per group into LDS -- or a z-score chunk B(k, c): read the same chunk back, z-score it
+        // with the arithmetic of fsst_normalize_kernel, store it for good (streaming).  Ticket order: all A(0, .); then
+        // for k = 1 .. nk-1 the first `lead` chunks of A(k, .), then B(k-1, 0), A(k, lead), B(k-1, 1), A(k, lead+1), ...
+        // and what is left of B(k-1, .); finally B(nk-1, .).  The wave that delivers the last group of a signal turns
+        // the signal's partials into {mean, 1/std} with signal_stats() -- the very function, order and data of the
+        // two-kernel path, hence bit-identical results -- while its siblings already transform the next signal; a B
+        // ticket waits (bounded) for that, which in the steady state it never has to: the B tickets of a signal start
+        // `lead` chunks after its last A ticket was handed out.
+        // Visibility: the un-normalised tile is written and read back by waves of ONE workgroup; the chain writer
+        // (release on the delivery counter) -> resolver (acquire / release on `ready`) -> reader (acquire) is
+        // workgroup scope, the waves share the CU's L1, and a line of `out` is read by this kernel exactly once.
+        // Slots: the partials of signal k live in LDS slot k & 1, written by the A(k, .) tickets and read once by the
+        // resolver of k.  A(k+2, .) tickets are handed out only after ALL NC tickets B(k, .) were handed out, and a B(k, .)
+        // ticket is held (waiting) until the resolver of k is done; the 15 waves other than the resolver cannot hold NC
+        // >= 16 of them, so slot reuse is safe by construction -- which is why the host sends signals of fewer than
+        // kFusedMinChunks chunks down the two-kernel path.  {mean, 1/std} are copied to registers at the start of a B
+        // ticket and live in 4 slots.
+        // (An earlier variant -- teams of 8 CUs per signal with the tile meant to stay in the XCD's L2 -- was built,
+        // bit-identical and slower; PMC showed that the L2 does not retain the written lines:
+        // profiles/r02_fused_team_variant.txt.)
+        // ------------------------------------------------------------------------------------------------
+        int c;
+        if (chunk < NC) {
+            ksig = 0; c = chunk;
+        } else {
+            const int u = chunk - NC;
+            const int kk = 1 + u / (2 * NC), v = u - (kk - 1) * (2 * NC);
+            if (kk < nk) {
+                const int npairs = NC - lead;
+                if (v < lead) { ksig = kk; c = v; }
+                else if (v - lead < 2 * npairs) {
+                    const int w = v - lead;
+                    if (w & 1) { ksig = kk; c = lead + (w >> 1); }
+                    else { ksig = kk - 1; c = w >> 1; zpass = true; }
+                } else { ksig = kk - 1; c = npairs + (v - lead - 2 * npairs); zpass = true; }
+            } else { ksig = nk - 1; c = v; zpass = true; }
         }
-        b = team + static_cast<long long>(it) * nteams;
-        grp0 = tw;
-        ngrp = (it < nk && tw < ngroups) ? 1 : 0;
+        b = static_cast<long long>(blockIdx.x) + ksig * gridDim.x;
+        grp0 = c * GPCF;
+        ngrp = min(GPCF, ngroups - grp0);
     } else {
         const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
         const int local = chunk - ((rg == 0) ? 0 : (rg == 1) ? nc0 : nc1);
@@ -492,38 +501,86 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         grp0 = p.reg.g0[rg] + cidx * gpc;
         ngrp = min(gpc, ngroups - grp0);
     }
+    // opaque copies of the lane coordinates for the HBM addressing below: otherwise the per-lane 64-bit address
+    // parts are hoisted out of the chunk loop, held in registers across it and spilled to scratch (a kernel with
+    // scratch costs isolated launches ~200 us on this runtime)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    int g_o = lane_o >> 4, j_o = lane_o & 15;
+    asm volatile("" : "+v"(g_o), "+v"(j_o));
+    const int g = FUSED ? (lane_o >> 4) : (lane >> 4), j = FUSED ? (lane_o & 15) : (lane & 15);   // (FUSED: re-derived per ticket, two registers fewer across the loop)
+    f2* row_disp = disp_base + j * LDF;
+    if (FUSED && zpass) {
+        // ---- B(ksig, c): z-score of ngrp groups of a signal whose statistics are (about to be) in LDS
+        const int sl = static_cast<int>(ksig) & 3;
+        const unsigned epoch = static_cast<unsigned>(ksig) + 1u;
+        const int C = 2 * K;
+        float4* d4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * C) + lane_o;
+        const int per = 8 * K;                           // float4 per full group = 16 * 2K / 4
+        for (unsigned spins = 0;; ++spins) {
+            unsigned have = 0;
+            if (lane == 0) have = __hip_atomic_load(ready + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(have) == epoch) break;
+            if (spins >= kSpinLimit || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if (lane == 0) {
+                    __hip_atomic_store((gu32*)(p.status), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float4 st = fin_stats[sl];
+        const unsigned cls = cls_lds[lane_o];
+        // One memory round trip per ticket: all 12 pieces (4 groups x 3 float4) of the chunk in flight at once.  The loads
+        // are unconditional (a lane without a piece re-reads the chunk's first float4): conditionally defined registers
+        // made the allocator spill here although 100 registers are free.
+        const float4* base0 = reinterpret_cast<const float4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * C);
+        auto glim = [&](int q) { return (q < ngrp) ? min(16, ncols - (grp0 + q) * 16) * (K >> 1) : 0; };
+        {
+            f4 o[GPCF][3];
+#pragma unroll
+            for (int q = 0; q < GPCF; ++q) {
+                const int lim = glim(q);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float4* src = (lane_o + 64 * i < lim) ? (d4 + q * per + 64 * i) : base0;
+                    o[q][i] = *reinterpret_cast<const f4*>(src);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GPCF; ++q) {
+                const int lim = glim(q);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (lane_o + 64 * i < lim) {
+                        const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
+                        const float m0 = im0 ? st.z : st.x, r0 = im0 ? st.w : st.y;
+                        const float m1 = im1 ? st.z : st.x, r1 = im1 ? st.w : st.y;
+                        f4 r;
+                        r.x = (o[q][i].x - m0) * r0; r.y = (o[q][i].y - m0) * r0;
+                        r.z = (o[q][i].z - m1) * r1; r.w = (o[q][i].w - m1) * r1;
+                        __builtin_nontemporal_store(r, reinterpret_cast<f4*>(d4 + q * per + 64 * i));
+                    }
+                }
+            }
+        }
+    } else {
     const float* xsig = p.x + b * p.xstride;
     auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
-        for (int i = lane; i < FPW + NWIN - 1; i += 64) {
+        for (int i = lane_o; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;
             xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
         }
     };
-    float wsum = 0.0f;                                   // FUSED: this wave's statistics partial of the signal
-    f2 pv = {0.0f, 0.0f};
-    int pcells = 0;                                      // FUSED: valid cells of this wave's piece
-    // opaque copies of the lane coordinates for the HBM addressing below: otherwise the per-lane 64-bit address
-    // parts are hoisted out of the chunk loop, held in registers across it and spilled to scratch (a kernel with
-    // scratch costs isolated launches ~200 us on this runtime)
-    int lane_o = lane, g_o = g, j_o = j;
-    asm volatile("" : "+v"(lane_o), "+v"(g_o), "+v"(j_o));
     for (int sub = 0; sub < ngrp; sub += FPW / 16) {
     const int t0 = p.col0 + (grp0 + sub) * 16;
-    PR_MARK(5)
-    if (FUSED && it > 0) {                               // the tile was fetched during the previous iteration's z-score
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (lane_o + 64 * i < FPW + NWIN - 1) xs[lane_o + 64 * i] = nx[i];
-            nx[i] = 0.0f;                                // (ends the live range: nothing is carried through the transform)
-        }
-    } else {
-        stage_tile(t0);
-    }
+    stage_tile(t0);
     wave_sync();
-    PR_MARK(0)
     const int gend = min(FPW / 16, ngrp - sub);
     for (int grp = 0; grp < gend; ++grp) {
-        const int tg = t0 + grp * 16;
+    const int tg = t0 + grp * 16;
         const int tr = tg - p.col0;
         // the tile's LDS byte address as ONE opaque register: every tap is then an immediate offset of it
         // (otherwise each merged ds_read2 gets its own "base + 0x2000 + tap" v_add).  Lane (kk = lane >> 4, f = lane & 15)
@@ -645,7 +702,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                     }
                 }
                 const float w = piece_sums(st_s.x, st_q.x, st_s.y, st_q.y);
-                if constexpr (FUSED) { wsum = w; pv = piv; pcells = nvalid * K; }
+                if constexpr (FUSED) store_partial(part_lds + ((static_cast<int>(ksig) & 1) * kFusedMaxGroups + gidx) * kPartFloats, w, piv.x, piv.y);
                 else store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
             }
             // the group's nvalid x 2K floats are contiguous in HBM: 16-byte stores, lane-linear; each float4 =
@@ -672,10 +729,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (lane + 64 * i < lim) {
-                    // FUSED: ordinary stores -- the un-normalised tile is meant to stay in this XCD's L2 until this
-                    // very lane reads it back.  Otherwise streaming stores: the features are not read again by this
-                    // kernel, and lines left dirty in L2 by 256 CUs that all write until the last microsecond cost
-                    // ~10 us of write-back after the kernel
+                    // FUSED: ordinary stores (a wave of this CU reads the tile back for the z-score).  Otherwise
+                    // streaming stores: the features are not read again by this kernel, and lines left dirty in L2 by
+                    // 256 CUs that all write until the last microsecond cost ~10 us of write-back after the kernel
                     if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
                     else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
                 }
@@ -730,187 +786,34 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         }
         wave_sync();
         if (wdirty) {
-            for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-            if (lane == 0) *flag = 0;
+            for (int i = lane_o; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+            if (lane_o == 0) *flag = 0;
             wave_sync();
         }
     }
     }
-    if constexpr (!FUSED) {
-        chunk = draw();
-    } else {
-        // ------------------------------------------------------------------------------------------------
-        // Fused z-score (FSST._stack_real_imag, synchrosqueeze.py:78-85, without a second pass over HBM).
-        // A TEAM of p.team CUs of one XCD computes one signal at a time, one 16-frame group per wave, and writes the
-        // un-normalised features with ordinary stores, so that they stay in the XCD's L2 (32 / team teams per XCD,
-        // three signals per team in flight: the one being computed and the two waiting for their statistics).
-        // Iteration `it` of a wave:
-        //   A(it)        compute its group of signal it; its piece's float64 moments go to an LDS slot, the last wave
-        //                of the CU to arrive adds the 16 slots in wave order and publishes the CU's block sum as eight
-        //                8-byte {tag, half of a double} granules (agent-scope atomic stores, tag = it + 1);
-        //   B(it - 2)    read back exactly the 16-byte pieces IT wrote two iterations ago (same lane, same address:
-        //                program order, no cross-CU visibility involved), z-score them with the statistics found in
-        //                LDS (arithmetic of fsst_normalize_kernel) and store them for good (streaming);
-        //   R(it - 1)    the FIRST wave of the CU to get here resolves signal it - 1 for its 15 siblings: polls the
-        //                granules of the team's CUs (published a whole iteration ago: one round trip), adds them in the
-        //                order of stats_from_blocks and leaves {mean, 1/std} in LDS for the next iteration's B.
-        // Nobody waits in the steady state: a resolver is ~3 us late for its next group, and the team needs that
-        // group's moments only an iteration later.  Only statistics cross CUs.  Ring depths (each follows from "a CU
-        // publishes it only when all of its waves finished iteration it - 1"): granules kFusedSlots = 5, LDS
-        // statistics 3, LDS moment slots 3.  Waves without a group keep the same pace (they wait in B like the rest).
-        // Every wait is bounded and reports through p.status instead of hanging.
-        // ------------------------------------------------------------------------------------------------
-        PR_MARK(1)
-        const int cu = bslot % tsize;
-        gu64* wsteam = (gu64*)(p.ws) + static_cast<size_t>(team) * kFusedSlots * tsize * 8;
-        if (it < nk) {
-            const int par = it % 3;
-            const int wbits = __float_as_int(wsum);      // (readlane is an integer builtin: pass bits, not values)
-            const float s1re = __int_as_float(__builtin_amdgcn_readlane(wbits, 0)), s2re = __int_as_float(__builtin_amdgcn_readlane(wbits, 16));
-            const float s1im = __int_as_float(__builtin_amdgcn_readlane(wbits, 32)), s2im = __int_as_float(__builtin_amdgcn_readlane(wbits, 48));
-            if (lane_o < 4) {
-                const bool im = lane_o >= 2;
-                cu_part[(par * WPB + wv) * 4 + lane_o] =
-                    piece_moment(lane_o, static_cast<double>(im ? s1im : s1re), static_cast<double>(im ? s2im : s2re),
-                                 static_cast<double>(im ? pv.y : pv.x), static_cast<double>(pcells));
-            }
-            unsigned arrived = 0;
-            if (lane == 0) arrived = __hip_atomic_fetch_add(cu_cnt + par, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            arrived = __builtin_amdgcn_readfirstlane(arrived);
-            if (arrived == static_cast<unsigned>(WPB - 1)) {
-                if (lane == 0) {
-                    __hip_atomic_store(cu_cnt + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(cu_done, static_cast<unsigned>(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (lane_o < 4) {
-                    double sum = 0.0;
-                    for (int w2 = 0; w2 < WPB; ++w2) sum += cu_part[(par * WPB + w2) * 4 + lane_o];
-                    const unsigned long long bits = __double_as_longlong(sum);
-                    const unsigned long long tag = static_cast<unsigned long long>(it + 1) << 32;
-                    gu64* gr = wsteam + (static_cast<size_t>(it % kFusedSlots) * tsize + cu) * 8 + lane_o * 2;
-                    __hip_atomic_store(gr, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(gr + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#ifdef HSS_FUSEPROBE
-                if (team == 0 && lane == 0 && it < 40) p.partials[65536 + (cu * 40 + it) * 4 + 0] = static_cast<float>(wall_clock64() & 0xffffff);
-#endif
-            }
-            // next signal's tile: issue the loads now, they land while this wave z-scores an older signal
-            if (it + 1 < nk && tw < ngroups) {
-                const float* xnext = p.x + (b + nteams) * p.xstride;
-                const int t0n = p.col0 + tw * 16;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int gi = t0n + lane_o + 64 * i - NWIN / 2;
-                    nx[i] = (lane_o + 64 * i < FPW + NWIN - 1 && gi >= 0 && gi < n) ? xnext[gi] : 0.0f;
-                }
-            }
-        }
-        // One attempt to resolve signal kp's statistics for this CU: true when they are in LDS afterwards.  One wave at a
-        // time (LDS lock); one look at the team's granules, no waiting here.
-        auto try_resolve = [&](int kp) -> bool {
-            const int sl = kp % 3;
-            const unsigned epoch = static_cast<unsigned>(kp + 1);
-            unsigned have = 0, busy = 1;
-            if (lane == 0) {
-                have = __hip_atomic_load(fin_epoch + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (have != epoch) busy = __hip_atomic_exchange(claim + sl, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            have = __builtin_amdgcn_readfirstlane(have);
-            if (have == epoch) return true;
-            if (__builtin_amdgcn_readfirstlane(busy) != 0) return false;           // a sibling is at it
-            // (the lock is ours; the statistics may have been published between the two looks above)
-            if (lane == 0) have = __hip_atomic_load(fin_epoch + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            have = __builtin_amdgcn_readfirstlane(have);
-            bool done = have == epoch;
-            if (!done) {
-                // lane (c, q) = (lane >> 2, lane & 3) fetches quantity q of the team's CUs c and c + 16
-                gu64* base = wsteam + static_cast<size_t>(kp % kFusedSlots) * tsize * 8 + (lane_o & 3) * 2;
-                const int c0 = lane_o >> 2;
-                unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-                bool ok = true;
-                if (c0 < tsize) {
-                    g0 = __hip_atomic_load(base + c0 * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g1 = __hip_atomic_load(base + c0 * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = static_cast<unsigned>(g0 >> 32) == epoch && static_cast<unsigned>(g1 >> 32) == epoch;
-                }
-                if (c0 + 16 < tsize) {
-                    g2 = __hip_atomic_load(base + (c0 + 16) * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g3 = __hip_atomic_load(base + (c0 + 16) * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && static_cast<unsigned>(g2 >> 32) == epoch && static_cast<unsigned>(g3 >> 32) == epoch;
-                }
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
-                    int ncols_o = ncols, K_o = K;        // opaque: keeps the float64 element count out of the loop-invariant
-                    asm volatile("" : "+s"(ncols_o), "+s"(K_o));   // set (hoisted, it is held across the transform and spilled)
-                    const float4 st = stats_from_blocks(tsize, static_cast<double>(K_o) * static_cast<double>(ncols_o), [&](int blk, int) {
-                        const unsigned long long lo = blk < 16 ? g0 : g2, hi = blk < 16 ? g1 : g3;
-                        return __longlong_as_double(static_cast<long long>((lo & 0xffffffffull) | (hi << 32)));
-                    });
-                    if (lane == 0) {
-                        fin_stats[sl] = st;
-                        __hip_atomic_store(fin_epoch + sl, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    done = true;
-                }
-            }
-            if (lane == 0) __hip_atomic_store(claim + sl, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            wave_sync();
-            return done;
-        };
-        if (it >= depth) {                               // ---- B(it - depth)
-            const bool mine = tw < ngroups;
-            const int kp = it - depth, sl = kp % 3;
-            const long long bp = team + static_cast<long long>(kp) * nteams;
-            const int C = 2 * K;
-            const int trp = tw * 16;
-            const int lim = mine ? min(16, ncols - trp) * (K >> 1) : 0;
-            float4* d4 = reinterpret_cast<float4*>(p.out + (bp * static_cast<long long>(ncols) + trp) * C) + lane_o;
-            f4 o[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (lane_o + 64 * i < lim) o[i] = *reinterpret_cast<const f4*>(d4 + 64 * i);
-            for (unsigned spins = 0;; ++spins) {         // (resolved an iteration ago: normally the first look succeeds)
-                if (try_resolve(kp)) break;
-                if (spins >= kSpinLimit || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    if (lane == 0) {
-                        __hip_atomic_store((gu32*)(p.status), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            PR_MARK(2)
-            const float4 st = fin_stats[sl];
-            const unsigned cls = cls_lds[lane_o];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (lane_o + 64 * i < lim) {
-                    const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
-                    const float m0 = im0 ? st.z : st.x, r0 = im0 ? st.w : st.y;
-                    const float m1 = im1 ? st.z : st.x, r1 = im1 ? st.w : st.y;
-                    f4 r;
-                    r.x = (o[i].x - m0) * r0; r.y = (o[i].y - m0) * r0;
-                    r.z = (o[i].z - m1) * r1; r.w = (o[i].w - m1) * r1;
-                    __builtin_nontemporal_store(r, reinterpret_cast<f4*>(d4 + 64 * i));
-                }
-            }
-        }
-        PR_MARK(3)
-        if (depth == 2 && it >= 1 && it <= nk) try_resolve(it - 1);    // ---- R(it - 1): one look, never a wait
-        PR_MARK(4)
-        ++it;
-    }
-    }
-#ifdef HSS_FUSEPROBE
     if constexpr (FUSED) {
-        if (lane == 0) {
-            float* o = p.partials + (static_cast<size_t>(blockIdx.x) * WPB + wv) * 8;
-            for (int i = 0; i < 6; ++i) o[i] = static_cast<float>(pr_acc[i]);
+        // ---- A(ksig, c) delivered: count its groups; whoever completes the signal resolves its statistics
+        const int sl = static_cast<int>(ksig) & 1;
+        unsigned before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(done_a + sl, static_cast<unsigned>(ngrp), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        before = __builtin_amdgcn_readfirstlane(before);
+        // (monotone counter: slot sl has seen the signals sl, sl + 2, ..., ksig; no reset, no window for a race)
+        if (before + static_cast<unsigned>(ngrp) == static_cast<unsigned>(ngroups) * (static_cast<unsigned>(ksig >> 1) + 1u)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int ncols_o = ncols, K_o = K, ng_o = ngroups;    // opaque: nothing of the float64 arithmetic below may be
+            asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(ng_o));   // hoisted out of the work loop (it would be spilled)
+            const float4 st = signal_stats(part_lds + sl * kFusedMaxGroups * kPartFloats, ng_o, 16, ncols_o, K_o, lane_o);
+            if (lane == 0) {
+                fin_stats[static_cast<int>(ksig) & 3] = st;
+                __hip_atomic_store(ready + (static_cast<int>(ksig) & 3), static_cast<unsigned>(ksig) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            wave_sync();
         }
     }
-#endif
+    }
+    chunk = draw();
+    }
 #ifdef HSS_CLOCKPROBE
     // development only (STACK_UNNORM, tools/clock_probe.py): HSS_CLOCKPROBE=1 -- shader-clock ticks and 100 MHz ticks one
     // wave in the middle of the grid lived; =2 -- start / end time (100 MHz ticks, low 32 bits) of every wave

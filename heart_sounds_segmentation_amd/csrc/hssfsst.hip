@@ -149,7 +149,6 @@ struct hssfsst_plan {
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
     int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
     float* d_partials = nullptr;  size_t partials_cap = 0;   // floats (kPartFloats per statistics piece)
-    unsigned long long* d_ws = nullptr; size_t ws_cap = 0;   // fused z-score: statistics granules (8 bytes each)
     unsigned* d_status = nullptr;                            // fused z-score: device status word (0 = ok)
     int last_fused = 0;                                      // the last exec ran the fused z-score kernel
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
@@ -240,45 +239,37 @@ int grow(void** ptr, size_t* cap, size_t need, size_t elem)
     return 0;
 }
 
-// Fused z-score launch (nwin = 128, STACK, wide-store epilogue; fsst_mfma128.hpp "Fused z-score").  Returns 1 when it
-// launched, 0 when this exec should take the two-pass path (signal too long for a team, batch too small to occupy the
-// teams, device smaller than expected), < 0 on error.
+// Fused z-score launch (nwin = 128, STACK, wide-store epilogue; fsst_mfma128.hpp "Fused z-score"): one persistent block
+// per CU, every CU owns whole signals.  Returns 1 when it launched, 0 when this exec should take the two-kernel path
+// (signal too long for the LDS partials, or a batch that would leave CUs idle for a whole signal), < 0 on error.
 template <int S1C>
 int launch_fused128(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st)
 {
-    constexpr int WPB = 16, FPW = 16;
-    int team = 1;
-    while (WPB * team < ngroups) team *= 2;
-    if (team > 32) return 0;
-    const size_t lds = (hssfsst::core128_atab_floats(8, 16) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
-                        hssfsst::wave_lds_floats(FPW, pl->klo, pl->K, 8, 16)) * sizeof(float);
+    constexpr int WPB = 16;
+    if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + kFpw128 / 16 - 1) / (kFpw128 / 16) < hssfsst::kFusedMinChunks) return 0;
+    const size_t lds = (hssfsst::core128_atab_floats(8, 16) + hssfsst::kCtlFusedFloats + static_cast<size_t>(WPB) *
+                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, 8, 16)) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    auto kern = hssfsst::fsst_core128_kernel<16, 8, FPW, true, WPB, S1C, true>;
+    auto kern = hssfsst::fsst_core128_kernel<16, 8, kFpw128, true, WPB, S1C, true>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
-    if (pl->fused_slots == 0) {                          // every block must be resident: the teams wait for each other
+    if (pl->fused_slots == 0) {
         int per_cu = 0, cus = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
         pl->fused_slots = (per_cu >= 1 && cus >= 1) ? cus : -1;       // one block per CU
     }
-    if (pl->fused_slots < 8 * team) return 0;
-    const int grid = (pl->fused_slots / (8 * team)) * (8 * team);
-    const int nteams = grid / team;
-    if (batch < 2 * static_cast<int64_t>(nteams)) return 0;           // too few signals to keep the teams busy
-    if (batch / nteams + 2 >= (1ll << 31)) return 0;
-    const size_t nws = static_cast<size_t>(nteams) * hssfsst::kFusedSlots * team * 8;    // [teams][slots][CUs of the team][8 granules]
-    int rc;
-    if ((rc = grow(reinterpret_cast<void**>(&pl->d_ws), &pl->ws_cap, nws, sizeof(unsigned long long))) != 0) return rc;
+    if (pl->fused_slots < 1) return 0;
+    // signals are dealt to the blocks round-robin and a signal is never split: the last round must be nearly full
+    // (a quarter-full last round of 4 costs 4 / 3.25 = 23 %), otherwise the chunk-balanced two-kernel path wins
+    const int64_t grid = pl->fused_slots;
+    const int64_t rounds = (batch + grid - 1) / grid;
+    if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (!pl->d_status) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_status), sizeof(unsigned)));
         HIP_TRY(hipMemset(pl->d_status, 0, sizeof(unsigned)));
     }
-    // every polled word is zeroed before every launch (tags count the team's signals from 1 within a launch)
-    HIP_TRY(hipMemsetAsync(pl->d_ws, 0, nws * sizeof(unsigned long long), st));
-    cp.ws = pl->d_ws; cp.status = pl->d_status; cp.team = team;
-    static const int tune = std::getenv("HSSFSST_FUSED_TUNE") ? std::atoi(std::getenv("HSSFSST_FUSED_TUNE")) : 0;
-    cp.tune = tune;
+    cp.status = pl->d_status;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -492,7 +483,6 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_ctab) (void)hipFree(p->d_ctab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
-    if (p->d_ws) (void)hipFree(p->d_ws);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
@@ -518,9 +508,6 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
     return 0;
 }
 
-#ifdef HSS_FUSEPROBE
-void* hssfsst_debug_partials(hssfsst_plan* p) { return p ? p->d_partials : nullptr; }
-#endif
 
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? 1 : 0; }
 

@@ -530,3 +530,28 @@ def test_bench_contract_json():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and d["value"] > 100 * c["value"] / c["cores"]
     assert "allgather_ms" in d["allgather"]
+
+
+@pytest.mark.parametrize("n,batch", [(2000, 1024), (2000, 517), (1999, 256), (1000, 300), (250, 512), (961, 512), (2048, 256), (33, 1024)])
+def test_fused_zscore_bit_identical_to_two_kernel_path(n, batch):
+    """The fused core + z-score kernel (one persistent block per CU, statistics resolved in LDS) against the
+    two-kernel path (HSSFSST_NO_FUSED=1 in a child process): same bits, for full and ragged last rounds, a partial
+    last group, the longest signal the fused kernel takes, and sizes where the library must fall back by itself."""
+    import subprocess, sys, tempfile
+    X = synth.noise_windows(batch, n, seed=n + batch)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    got = tf.batch(torch.from_numpy(X).cuda())
+    fused = tf.check()                                    # raises if a wait inside the kernel gave up
+    rounds = -(-batch // 256)
+    assert fused == (961 <= n <= 2048 and batch >= 256 and rounds * 256 * 100 <= batch * 112) or torch.cuda.get_device_properties(0).multi_processor_count != 256
+    got = got.cpu().numpy()
+    with tempfile.TemporaryDirectory() as td:
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
+                "from heart_sounds_segmentation_amd import FSST, synth; "
+                "X = synth.noise_windows(%d, %d, seed=%d); "
+                "tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True); "
+                "y = tf.batch(torch.from_numpy(X).cuda()); assert not tf.check(); np.save(%r, y.cpu().numpy())"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), batch, n, n + batch, os.path.join(td, "ref.npy")))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HSSFSST_NO_FUSED="1"), timeout=600)
+        ref = np.load(os.path.join(td, "ref.npy"))
+    assert np.array_equal(got, ref, equal_nan=True)
