@@ -1,16 +1,22 @@
 """Rolling (streaming) FSST for multi-channel PCG -- BASELINE.json config 5 / SURVEY section 8f row 3.
 
 Not in the reference (which only transforms stored recordings, hss/datasets/heart_sounds.py:155-184);
-built from the same path: per channel a ring of the last ``nwin - 1`` samples, every ``step`` of
+built from the same path: per channel the last ``nwin - 1`` samples are kept, every ``step`` of
 ``chunk`` new samples emits the ``chunk`` FSST columns whose full frames are now available (look-ahead
-latency ``nwin/2 - 1`` samples) through ``hssfsst_exec_cols`` (no frame touches zero padding), and
+latency ``nwin/2 - 1`` samples) through ``hssfsst_exec_frames`` (no frame touches zero padding), and
 -- because a per-signal z-score has no streaming meaning -- normalises with RUNNING mean / unbiased
 std of the real and imaginary blocks, kept on the device by ``hssfsst_moments_merge`` (the chunked
 form of ``hss.moments.update_mean / update_variance``, hss/moments/__init__.py:1-36).
 
-Concatenating the un-normalised outputs of consecutive steps (zero initial ring) reproduces the
+Concatenating the un-normalised outputs of consecutive steps (zero initial history) reproduces the
 offline transform's columns ``-nwin/2 + 1, ..`` exactly: column tau of the offline, zero-padded FSST
 is column ``tau + nwin/2 - 1`` of the stream.
+
+No allocation per step: the history lives in ONE preallocated device buffer per channel of
+``nwin - 1 + slots * chunk`` samples that is written like a tape -- each step appends its chunk and
+transforms the last ``nwin - 1 + chunk`` samples in place (``x_stride`` = tape length); only when the
+tape is full (every ``slots`` steps) the last ``nwin - 1`` samples are copied back to its start.  The
+feature output and the pinned host staging buffers of ``step_host`` are preallocated too.
 """
 from __future__ import annotations
 
@@ -26,34 +32,70 @@ from .transforms.synchrosqueeze import FSST
 
 class StreamingFSST:
     def __init__(self, channels: int, fs: float, window, truncate_freq: Optional[tuple] = None,
-                 chunk: int = 128, normalize: bool = True, device: Optional[torch.device] = None):
+                 chunk: int = 128, normalize: bool = True, device: Optional[torch.device] = None,
+                 slots: int = 64):
         self.tf = FSST(fs, window, truncate_freq=truncate_freq, stack=True, device=device)
         self.nwin = int(np.asarray(window).size)
         self.channels, self.chunk, self.normalize = int(channels), int(chunk), bool(normalize)
         dev = self.tf._device_index()
         self.device = torch.device("cuda", dev)
-        self.ring = torch.zeros((self.channels, self.nwin - 1), dtype=torch.float32, device=self.device)
+        self.hist = self.nwin - 1
+        self.slots = max(1, int(slots))
+        self.tape_len = self.hist + self.slots * self.chunk
+        self.tape = torch.zeros((self.channels, self.tape_len), dtype=torch.float32, device=self.device)
+        self._wrap = torch.empty((self.channels, self.hist), dtype=torch.float32, device=self.device)
+        self.pos = self.hist                               # where the next chunk goes (history = zeros before it)
         self.state = torch.zeros((self.channels, 6), dtype=torch.float64, device=self.device)
         self.latency_samples = self.nwin // 2 - 1
+        self._plan = self.tf._plan(dev, _lib.MODE_STACK_UNNORM)
+        self.K = self._plan.K
+        self.out = torch.empty((self.channels, self.chunk, 2 * self.K), dtype=torch.float32, device=self.device)
+        self._pin_in = None
+        self._pin_out = None
+
+    # kept for callers / tests that looked at the history of the first implementation
+    @property
+    def ring(self) -> torch.Tensor:
+        return self.tape[:, self.pos - self.hist:self.pos]
 
     def step(self, x_new: torch.Tensor) -> torch.Tensor:
         """``x_new``: ``(channels, chunk)`` newest samples (device tensor preferred).  Returns
         ``(channels, chunk, 2K)`` features of the columns centred ``nwin/2 - 1`` samples before the
-        newest sample and earlier."""
+        newest sample and earlier.  The returned tensor is this object's output buffer: it is
+        overwritten by the next step."""
         if tuple(x_new.shape) != (self.channels, self.chunk):
             raise ValueError(f"StreamingFSST.step: expected {(self.channels, self.chunk)}, got {tuple(x_new.shape)}")
-        x_new = x_new.to(device=self.device, dtype=torch.float32)
-        buf = torch.cat([self.ring, x_new], dim=1).contiguous()
-        feats = self.tf.unnormalized(buf, cols=(self.nwin // 2, self.chunk))
-        self.ring = buf[:, self.chunk:].contiguous()
+        if self.pos + self.chunk > self.tape_len:          # tape full: history back to the start (every `slots` steps)
+            self._wrap.copy_(self.tape[:, self.pos - self.hist:self.pos])     # (two hops: the ranges may overlap)
+            self.tape[:, :self.hist].copy_(self._wrap)
+            self.pos = self.hist
+        self.tape[:, self.pos:self.pos + self.chunk].copy_(x_new, non_blocking=True)
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        n_in = self.hist + self.chunk
+        x0 = self.tape.data_ptr() + 4 * (self.pos - self.hist)
+        _lib.check(L.hssfsst_exec_frames(self._plan.handle, ctypes.c_void_p(x0), self.channels, n_in, self.tape_len,
+                                         self.nwin // 2, self.chunk, 1, ctypes.c_void_p(self.out.data_ptr()), 1, stream),
+                   "hssfsst_exec_frames")
+        self.pos += self.chunk
         if self.normalize:
-            L = _lib.lib()
-            plan = self.tf._plan(self.device.index, _lib.MODE_STACK_UNNORM)
-            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _lib.check(L.hssfsst_moments_merge(plan.handle, ctypes.c_void_p(feats.data_ptr()), self.channels,
+            _lib.check(L.hssfsst_moments_merge(self._plan.handle, ctypes.c_void_p(self.out.data_ptr()), self.channels,
                                                self.chunk, ctypes.c_void_p(self.state.data_ptr()), stream),
                        "hssfsst_moments_merge")
-            _lib.check(L.hssfsst_normalize_running(plan.handle, ctypes.c_void_p(feats.data_ptr()), self.channels,
+            _lib.check(L.hssfsst_normalize_running(self._plan.handle, ctypes.c_void_p(self.out.data_ptr()), self.channels,
                                                    self.chunk, ctypes.c_void_p(self.state.data_ptr()), stream),
                        "hssfsst_normalize_running")
-        return feats
+        return self.out
+
+    def step_host(self, x_new: np.ndarray) -> np.ndarray:
+        """Host in, host out (the latency BASELINE config 5 asks for: last sample of a chunk on the host ->
+        its features on the host): pinned staging buffers, one H2D copy, the kernels, one D2H copy, one
+        synchronisation.  Returns a view of the pinned output buffer (overwritten by the next call)."""
+        if self._pin_in is None:
+            self._pin_in = torch.empty((self.channels, self.chunk), dtype=torch.float32).pin_memory()
+            self._pin_out = torch.empty((self.channels, self.chunk, 2 * self.K), dtype=torch.float32).pin_memory()
+        self._pin_in.numpy()[...] = x_new
+        feats = self.step(self._pin_in)
+        self._pin_out.copy_(feats, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._pin_out.numpy()

@@ -411,8 +411,12 @@ def test_streaming_matches_offline(oracle_mod):
     fs, N, chunk, ch, steps = 4000, 512, 128, 64, 6
     w = get_window(("kaiser", 0.5), N, fftbins=False)
     x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=3)
-    st = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=False)
-    outs = [st.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda()) for i in range(steps)]
+    st = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=False, slots=4)   # the tape wraps once
+    outs = [st.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda()).clone() for i in range(steps)]
+    # host in / host out (pinned staging, the latency path of bench.py --config c5) gives the same numbers
+    sth = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=False, slots=2)
+    for i in range(steps):
+        assert np.array_equal(sth.step_host(x[:, i * chunk:(i + 1) * chunk]), outs[i].cpu().numpy())
     stream = torch.cat(outs, dim=1).cpu().numpy()                      # (ch, steps*chunk, 44)
     assert stream.shape == (ch, chunk * steps, 44) and st.latency_samples == 255
     # offline columns tau = 0 .. T - N/2 are stream columns tau + N/2 - 1
@@ -429,7 +433,7 @@ def test_streaming_matches_offline(oracle_mod):
     st2 = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True)
     seen = []
     for i in range(3):
-        y = st2.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda())
+        y = st2.step(torch.from_numpy(x[:, i * chunk:(i + 1) * chunk]).cuda()).clone()
         seen.append(outs[i])
         allre = torch.cat(seen, dim=1)[..., :22].double()
         m = allre.mean(dim=(1, 2), keepdim=True)

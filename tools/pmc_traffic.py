@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""profiles/rNN_pmc_traffic.json from a tools/rocprof_summary.py summary (FETCH_SIZE / WRITE_SIZE passes).
+"""profiles/rNN_pmc.json from a tools/rocprof_summary.py summary (separate --pmc passes).
 usage: pmc_traffic.py summary.json out.json
-Counter values are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950."""
-import json, sys
-s = json.load(open(sys.argv[1]))["pmc_avg_per_dispatch"]
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 5 --warmup 1 "
-                 "--settle-steps 0 --no-cpu-baseline` (tools/profile_round.sh)",
-       "units": "counter values are KiB; bytes = value * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
-                "half of a streaming read; dword-wide reads here, so the read side is approximate)"}
-for name, v in s.items():
-    if "FETCH_SIZE" not in v or "rocclr" in name:
+Counter values of FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
+(it reports half of a wide streaming read).  The file is keyed to the SHA-256 of the kernel sources it was measured
+on; bench.py quotes it only for that binary."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+s = json.load(open(sys.argv[1]))
+out = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ instruction mix | SQ wait/busy + MFMA | TCC hit/miss, one pass each) of "
+                 "`python bench.py --steps 5 --warmup 1 --settle-steps 0 --no-cpu-baseline` (tools/profile_round.sh); averages per dispatch",
+       "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 reports half of a wide "
+                "streaming read: MI355X_MICROARCH.md); SQ_* are wave-instruction / quad-cycle counts summed over the launch",
+       "csrc_sha256": bench.csrc_digest(), "kernels": {}}
+for name, v in s.get("pmc_avg_per_dispatch", {}).items():
+    if "hssfsst" not in name:
         continue
-    key = "fsst_core128_kernel" if "core128" in name else name.split("::")[-1].split("(")[0]
-    e = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
-         "hbm_bytes_per_launch": int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))}
-    if "core128" in name:
-        e["algorithmic_bytes_per_launch"] = 360000 * 1024
-    out[key] = e
+    e = dict(v)
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        e["hbm_bytes_per_launch"] = int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
+    out["kernels"][name] = e
+out["kernel_trace_stats"] = s.get("kernel_trace_stats")
 json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps(out, indent=1)[:3000])
