@@ -49,6 +49,9 @@ struct CoreParams {
     int col0;             // first output column (frame centre) of every signal
     int ncols;            // number of output columns (== n for a whole-signal transform)
     int oneplane;         // 1: own and displaced values share one LDS plane (wide bands)
+    const double* wtab;   // float64 tables of the rounding-tie path (see Scatter)
+    const double* twtab;
+    float r2scale;
     long long xstride;    // samples between the starts of consecutive signals (n for a dense batch; smaller for
                           // overlapping frames of one recording, hss/utils/preprocess.py:48-52)
 };
@@ -139,6 +142,10 @@ struct Scatter {
     int klo;
     int K;
     bool oneplane;        // own == disp (wide bands that do not fit two planes in LDS): own-row values are accumulated
+    const float* frame;   // this lane's frame in the LDS tile: frame[n] = sample n of the zero-padded hop-1 frame
+    const double* wtab;   // float64 {w, dw' (bin units)}[nwin]       } rounding ties, see scatter_source
+    const double* twtab;  // float64 {cos, sin}(2 pi m / nwin)[nwin]  }
+    float R2;             // error-bound scale of this tile (see fsst_mfma128.hpp "Rounding ties")
     __device__ __forceinline__ void add(int row, float re, float im) const
     {
         const int idx = row - klo;
@@ -158,13 +165,18 @@ struct Scatter {
 // mirror then lands in row nwin - k' > nwin/2, outside every kept band.  V == 0 contributes 0
 // wherever it lands and is treated as staying.  Only when some lane of the wave has a displaced
 // cell does the wave run the exact rounding path for those lanes.
+constexpr float kTieMarginG = 1.0f / 64.0f;      // (== kTieMargin, kTieErr2, kTieFloor2 of fsst_mfma128.hpp, where the
+constexpr float kTieErr2G = 1.6e-13f;            //  error model behind them is described)
+constexpr float kTieFloor2G = 1.0e-10f;
+
 template <int NWIN, int LD>
 __device__ __forceinline__ void scatter_source(const Scatter<LD>& sc, float kp, int kpi, float sgn,
                                                bool mirror, float p, float q, float u, float v)
 {
     const float den = fmaf(p, p, q * q);
     const float num = fmaf(u, q, -(v * p));
-    const bool moved = (fabsf(num) >= 0.5f * den) && (den > 0.0f);
+    // (threshold kTieMarginG below 1/2: a |shift| that close to 1/2 is a rounding tie too and is decided in float64 below)
+    const bool moved = (fabsf(num) >= (0.5f - kTieMarginG) * den) && (den > 0.0f);
     const float re = sgn * p, im = sgn * q;
     const int slot = kpi - sc.klo;                        // wave-uniform
     if (static_cast<unsigned>(slot) < static_cast<unsigned>(sc.K)) {
@@ -180,7 +192,26 @@ __device__ __forceinline__ void scatter_source(const Scatter<LD>& sc, float kp, 
         float shift = num * __builtin_amdgcn_rcpf(den);
         if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;      // inf / absurd -> 0 (fsst.m: ~isfinite)
         const float a = kp + shift;
-        const float r = truncf(a + copysignf(0.5f, a));
+        float r = truncf(a + copysignf(0.5f, a));
+        const float fr = a - floorf(a) - 0.5f, s1 = 1.0f + fabsf(shift);
+        if (fr * fr * den < kTieErr2G * s1 * s1 * sc.R2 && den > kTieFloor2G * sc.R2) {
+            // Rounding too close to call in float32 (its estimate of the shift is off by up to ~1e-2 bins for a small
+            // cell that moves far): this bin of V and Vd' again by a float64 DFT of the lane's frame, float64 coordinate,
+            // MATLAB round.  Divergent and slow (nwin taps), but only such cells pay.
+            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+            for (int n = 0; n < NWIN; ++n) {
+                const double x = static_cast<double>(sc.frame[n]);
+                const double2 wd = reinterpret_cast<const double2*>(sc.wtab)[n];
+                const double2 cs = reinterpret_cast<const double2*>(sc.twtab)[(kpi * n) & (NWIN - 1)];
+                const double xw = x * wd.x, xd = x * wd.y;
+                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+            }
+            double sh = (dr * vi - di * vr) / (vr * vr + vi * vi);
+            if (!(fabs(sh) <= 1.0e6)) sh = 0.0;
+            const double ad = static_cast<double>(kpi) + sh;
+            r = static_cast<float>((ad >= 0.0) ? floor(ad + 0.5) : -floor(0.5 - ad));
+        }
         const int row = static_cast<int>(r) & (NWIN - 1);
         sc.add(row, re, im);
         if (mirror) sc.add((NWIN - row) & (NWIN - 1), re, -im);
@@ -414,16 +445,20 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const float* xsig = p.x + b * p.xstride;
 
     // stage the zero-padded signal tile: xs[i] = xpad[t0 + i] = x[t0 + i - nwin/2]
+    float e2 = 0.0f;                                     // sum x^2 of the tile: error-bound scale of displaced cells
     for (int i = tid; i < TILE + NWIN - 1; i += TILE) {
         const int g = t0 + i - NWIN / 2;
-        xs[i] = (g >= 0 && g < n) ? xsig[g] : 0.0f;
+        const float v = (g >= 0 && g < n) ? xsig[g] : 0.0f;
+        xs[i] = v;
+        e2 = fmaf(v, v, e2);
     }
+    const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
     const bool oneplane = p.oneplane != 0;
     float* disp = oneplane ? own : own + 2 * K * LD;
     for (int c = 0; c < 2 * K; ++c) disp[c * LD + tid] = 0.0f;
     __syncthreads();
 
-    const Scatter<LD> sc{own + tid, disp + tid, p.klo, K, oneplane};
+    const Scatter<LD> sc{own + tid, disp + tid, p.klo, K, oneplane, xs + tid, p.wtab, p.twtab, R2};
     const float* myx = xs + tid;
     ctab_ptr tab = (ctab_ptr)p.ctab;
     packed_class<R, false, LD>(tab, myx, sc);

@@ -63,6 +63,9 @@ struct Core128Params {
     float* out;
     float* partials;      // [batch][groups][kPartFloats], one statistics partial per 16-frame group of the signal
     const float* atab;    // MFMA A-operand constants [16 taps][2 k-halves][64 lanes], then the FAST store offsets
+    const double* wtab;   // float64 {w, dw' (bin units)}[nwin]        } the rounding-tie path (resolve_ties)
+    const double* twtab;  // float64 {cos, sin}(2 pi m / nwin)[nwin]   }
+    float r2scale;        // 4 nwin max_n |(w + i dw') / 2|^2[n]: R^2 = r2scale * sum x^2 over a tile bounds |V|^2 sums
     int n;
     int klo;
     int K;
@@ -217,7 +220,8 @@ __host__ __device__ constexpr int own_ld(int klo, int K, int rq = 8)
 // MFMA A-operand constants: [pass][nt taps][k-step][64 lanes] floats, rq / 8 passes of rq / 4 k-steps
 __host__ __device__ constexpr int core128_atab_floats(int rq = 8, int nt = 16) { return (rq / 8) * nt * (rq / 4) * 64; }
 constexpr int kMaxWavesPerBlock = 16;        // 16 = one block owns a whole CU (4 waves per SIMD); fewer when LDS is short
-constexpr int kCtlFloats = 16;               // block control words in LDS: [0] work counter
+constexpr int kCtlFloats = 16 + 192;         // block control words in LDS: [0] work counter, [16..207] the wide-store offset
+                                             // table (3 words per lane: held in registers it costs the 16-wave kernels a spill)
 // FUSED kernel: [0] ticket counter, [1..2] groups delivered per signal slot (monotone), [3] a wait gave up, [4..7] epoch
 // of the resolved statistics (4 slots), [8..15] (unused), [16..79] per-lane column classes of the z-score
 // pass, [80..271] the wide-store offset table (3 words per lane; the fused kernel has no register to spare for it),
@@ -242,9 +246,28 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
             tab[(3 + i) * 64 + lane] = (c + 2 < K) ? (rowb + c + 2) * 8 : (rowb + c + 2 - K) * 8 + 4;
         }
 }
+// Rounding ties.  A displaced source lands in row round(k' + shift).  The float32 estimate of the shift carries an
+// error of ~1e-7 (1 + |shift|) max|Z| / |V|: for a cell that is small against its frame's spectrum and moves tens of
+// bins (Hann-, Blackman-, Kaiser(beta >> 1)-class windows) that is up to ~1e-2 bins, enough to put the cell into the
+// neighbouring row of the float64 reference.  The kernel therefore carries an error bound with every displaced cell:
+// with R^2 = 4 nwin max|c|^2 sum x^2 over the staged tile (Parseval: an upper bound of sum |Z|^2 of every frame of the tile,
+// c = (w + i dw') / 2) the coordinate is good to about  tau = kTieErr (1 + |shift|) R / |V|.  A displaced cell whose float32
+// coordinate lies within tau of a half-integer is NOT moved on the spot: it goes to a per-wave queue in LDS (frame, bin,
+// value) and, once the group's spectra are done and their registers free, the whole wave recomputes that one bin of V
+// and Vd' by a float64 DFT of the frame (two taps per lane for nwin = 128, window and twiddle tables in float64 from
+// HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below kTieFloor R are left to float32: they
+// cannot change a feature by 1e-5 of the frame's spectrum norm wherever they land.  Large cells have tau ~ 1e-6 and are
+// practically never queued; the queue holds the small far-moving cells that float32 cannot place.
+constexpr int kTieQueue = 32;                // entries per wave and 16-frame group; overflow falls back to float32
+constexpr int kTieWords = 4 + 3 * kTieQueue; // [0] count, [4 + 3 e ..] = {bin | frame << 16, V.re, V.im}
+constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
+constexpr float kTieErr2 = 1.6e-13f;         // (4e-7)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2
+constexpr float kTieFloor2 = 1.0e-10f;       // (1e-5)^2: cells with |V|^2 below this times R^2 stay with float32
+
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8, int nt = 16)
 {
-    return ((fpw + nt * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4;   // + dirty flag
+    return ((fpw + nt * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4   // + dirty flag
+           + kTieWords;                                                                              // + tie queue
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -254,25 +277,18 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// Exact (rare) path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32.  `row_disp`
-// points at this lane's frame row in the displaced plane; the own plane already holds V in the
-// source's own column (unconditional store), so V is first taken out again there.
+// Moves a source k' -> row in a frame's displaced plane: the own plane holds V in the source's own column
+// (unconditional store), so V is taken out again there, added at `row` and -- conjugated -- at the negative-frequency
+// twin's row nwin - row (oracle/fsst_oracle.c step 6: two-sided cyclic scatter, one-sided rows kept).
 template <int NWIN>
-__device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int klo, int K, int kpi,
-                                                 float num, float den, f2 V)
+__device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V)
 {
-    const float kf = static_cast<float>(kpi);
     auto add = [&](int idx, float re, float im) {
         float* q = reinterpret_cast<float*>(row_disp + idx);
         __hip_atomic_fetch_add(q, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         *flag = 1;                                      // this wave's displaced plane is no longer zero
     };
-    float shift = num * __builtin_amdgcn_rcpf(den);
-    if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
-    const float a = kf + shift;
-    const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    const int row = static_cast<int>(r) & (NWIN - 1);
     if (row == kpi) return;                             // rounds back into its own row after all
     const int own = kpi - klo, idx = row - klo;
     if (static_cast<unsigned>(own) < static_cast<unsigned>(K)) add(own, -V.x, -V.y);
@@ -281,6 +297,69 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
         const int idm = ((NWIN - row) & (NWIN - 1)) - klo;      // row -> nwin - row, value conj
         if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) add(idm, V.x, -V.y);
     }
+}
+
+// Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
+// rounding tie, which are queued for resolve_ties().  `row_disp` points at this lane's frame row (frame j of the
+// group) in the displaced plane.
+template <int NWIN>
+__device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* tq, int klo, int K, int kpi, int j,
+                                                 float num, float den, f2 V, float R2)
+{
+    float shift = num * __builtin_amdgcn_rcpf(den);
+    if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
+    const float a = static_cast<float>(kpi) + shift;
+    const float fr = a - floorf(a) - 0.5f, s1 = 1.0f + fabsf(shift);
+    if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
+        const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (slot < kTieQueue) {
+            tq[4 + 3 * slot] = kpi | (j << 16);
+            tq[5 + 3 * slot] = __float_as_int(V.x);
+            tq[6 + 3 * slot] = __float_as_int(V.y);
+            return;
+        }
+    }
+    const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
+    move_source<NWIN>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V);
+}
+
+// The whole wave, after the group's spectra: every queued cell's bin of V and Vd' by a float64 DFT of its frame
+// (xg = the group's first frame in the LDS tile; wtab[n] = {w, dw'}[n], twtab[m] = {cos, sin}(2 pi m / nwin), float64),
+// the float64 coordinate k' - Im(Vd'/V) rounded half away from zero, then the move.
+template <int NWIN>
+__device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                             const double* wtab, const double* twtab, int lane)
+{
+    const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueue);
+    for (int e = 0; e < qn; ++e) {
+        const int meta = __builtin_amdgcn_readfirstlane(tq[4 + 3 * e]);
+        const int kpi = meta & 0xffff, jf = meta >> 16;
+        double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+        for (int n = lane; n < NWIN; n += 64) {
+            const double x = static_cast<double>(xg[jf + n]);
+            const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+            const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+            const double xw = x * wd.x, xd = x * wd.y;
+            vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+            dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
+            dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
+        }
+        if (lane == 0) {
+            const double den = vr * vr + vi * vi;
+            double shift = (dr * vi - di * vr) / den;
+            if (!(fabs(shift) <= 1.0e6)) shift = 0.0;   // V == 0 or absurd -> 0 (fsst.m: ~isfinite)
+            const double a = static_cast<double>(kpi) + shift;
+            const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+            const f2 V = {__int_as_float(tq[5 + 3 * e]), __int_as_float(tq[6 + 3 * e])};
+            move_source<NWIN>(disp_base + jf * LDF, flag, klo, K, kpi, static_cast<int>(static_cast<long long>(r)) & (NWIN - 1), V);
+        }
+    }
+    if (lane == 0) tq[0] = 0;
 }
 
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner
@@ -297,7 +376,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int kl
 // further gain).
 template <int S, int RQ, int NWIN>
 __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 tiny, f2* ownA, f2* ownB, bool store,
-                                               f2* row_disp, int* flag, int klo, int K, int rA, int rB)
+                                               f2* row_disp, int* flag, int* tq, int j, int klo, int K, int rA, int rB, float R2)
 {
     const f2 a1 = mix_re(XA, PA), a2 = mix_im(XA, PA);
     const f2 b1 = mix_re(XB, PB), b2 = mix_im(XB, PB);
@@ -308,10 +387,13 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
         qa[0] = a1.x; qa[1] = a2.x;
         qb[0] = b1.x; qb[1] = b2.x;
     }
-    const bool ma = fabsf(dna.y) >= 0.5f * dna.x, mb = fabsf(dnb.y) >= 0.5f * dnb.x;
+    // (the threshold sits kTieMargin below 1/2 so that a cell whose |shift| is within the margin of 1/2 -- a rounding
+    //  tie as well -- reaches the rare path and its float64 decision)
+    constexpr float kStay = 0.5f - kTieMargin;
+    const bool ma = fabsf(dna.y) >= kStay * dna.x, mb = fabsf(dnb.y) >= kStay * dnb.x;
     if (ma | mb) {                                      // skipped when no lane moved (execz)
-        if (ma) displaced_source<NWIN>(row_disp, flag, klo, K, rA + RQ * S, dna.y, dna.x, f2{a1.x, a2.x});
-        if (mb) displaced_source<NWIN>(row_disp, flag, klo, K, rB + RQ * S, dnb.y, dnb.x, f2{b1.x, b2.x});
+        if (ma) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2);
+        if (mb) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2);
     }
 }
 
@@ -368,13 +450,14 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     unsigned* ready = dead + 1;                                              // FUSED: [4] epoch of fin_stats[]
     float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + 272);        // FUSED: [4] resolved statistics
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // FUSED: [64] see "cls" below
-    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // FUSED: [3][64] wide-store offsets
+    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + (FUSED ? 80 : 16));   // [3][64] wide-store offsets (FAST)
     float* part_lds = smem + ATAB + 288;                                     // FUSED: [2][kFusedMaxGroups][kPartFloats]
     float* wbase = smem + ATAB + CTL + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
+    int* tq = flag + 4;                                                       // rounding-tie queue (kTieWords)
 
     // shared MFMA A operand, regrouped so that a lane reads all k-steps of a tap with one LDS instruction:
     // global [pass * 16 + tap][k-step][lane]  ->  LDS [pass * 16 + tap][lane][k-step]
@@ -384,7 +467,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane == 0) *flag = 0;
+    if (lane == 0) { *flag = 0; tq[0] = 0; }
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
     if constexpr (FUSED) {
         if (wv == 0) {
@@ -398,6 +481,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
             }
             cls_lds[lane] = cls;
+        }
+    }
+    // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group): every lane's six LDS byte
+    // offsets of the store pass (host-made table, core128_store_offsets), two 16-bit offsets per word
+    if constexpr (FAST) {
+        if (wv == 0) {
             const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -430,16 +519,6 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     const float* myA = atab + lane * KST;
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
-    // wide-store epilogue (time-major [re | im] rows, K even, <= 3 float4 per lane and group):
-    // this lane's six LDS byte offsets of the store pass (host-made table, core128_store_offsets), two 16-bit
-    // offsets per register: three VGPRs for the whole kernel (six pushed the register allocation into scratch)
-    unsigned ppk[3] = {0u, 0u, 0u};
-    if constexpr (FAST && !FUSED) {
-        const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            ppk[i] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
-    }
     while (chunk < nwork) {
     // decode: signal, first group, number of groups
     long long b;
@@ -508,7 +587,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     asm volatile("" : "+v"(lane_o));
     int g_o = lane_o >> 4, j_o = lane_o & 15;
     asm volatile("" : "+v"(g_o), "+v"(j_o));
-    const int g = FUSED ? (lane_o >> 4) : (lane >> 4), j = FUSED ? (lane_o & 15) : (lane & 15);   // (FUSED: re-derived per ticket, two registers fewer across the loop)
+    const int g = lane_o >> 4, j = lane_o & 15;          // (re-derived per work item: two registers fewer across the loop)
     f2* row_disp = disp_base + j * LDF;
     if (FUSED && zpass) {
         // ---- B(ksig, c): z-score of ngrp groups of a signal whose statistics are (about to be) in LDS
@@ -568,15 +647,20 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
-    auto stage_tile = [&](int t0) {                      // xs[i] = xpad[t0 + i] = x[t0 + i - 64]
+    auto stage_tile = [&](int t0) -> float {             // xs[i] = xpad[t0 + i] = x[t0 + i - 64]; returns sum x^2 (per lane)
+        float e = 0.0f;
         for (int i = lane_o; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;
-            xs[i] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+            const float v = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+            xs[i] = v;
+            e = fmaf(v, v, e);
         }
+        return e;
     };
     for (int sub = 0; sub < ngrp; sub += FPW / 16) {
     const int t0 = p.col0 + (grp0 + sub) * 16;
-    stage_tile(t0);
+    // R^2 of the tile's frames for the error bound of displaced cells (see "Rounding ties")
+    const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(stage_tile(t0), 0.0f, 0.0f, 0.0f))));
     wave_sync();
     const int gend = min(FPW / 16, ngrp - sub);
     for (int grp = 0; grp < gend; ++grp) {
@@ -653,7 +737,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 PA = pb; PB = pa;
             }
             const bool st = (s >= s0) && (s <= s1);
-            process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, klo, K, rAi, rBi);
+            process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, tq, j, klo, K, rAi, rBi, R2);
         });
         // k' = nwin/2 (class 0, j = 8) is its own partner: V = 2 Re(Z[nwin/2]) is real, its shift is exactly 0
         if constexpr (pz == 0) {
@@ -662,6 +746,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
 #endif
         });
         wave_sync();
+        if (__builtin_amdgcn_readfirstlane(tq[0]) != 0) {    // (rare) cells whose rounding float32 cannot decide
+            resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, p.wtab, p.twtab, lane_o);
+            wave_sync();
+        }
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
         const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
@@ -718,7 +806,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
             {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const unsigned pk = FUSED ? ppk_lds[i * 64 + lane_o] : ppk[i];
+                const unsigned pk = ppk_lds[i * 64 + lane_o];
                 const int p0 = static_cast<int>(pk & 0xffffu), p1 = static_cast<int>(pk >> 16);
                 o[i].x = *reinterpret_cast<const float*>(ob + p0);
                 o[i].y = *reinterpret_cast<const float*>(ob + p0 + 8);
@@ -739,7 +827,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
             }
         } else if (p.mode == kModeRaw) {
             float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(ncols) + tr;
-            for (int e = lane_o; e < K * 16; e += 64) {
+            int e0 = lane_o;                                 // opaque per GROUP (see the general epilogue below)
+            asm volatile("" : "+v"(e0));
+            for (int e = e0; e < K * 16; e += 64) {
                 const int k = e >> 4, jj = e & 15;
                 if (jj < nvalid) {
                     f2 v = own_base[jj * OLD + koff + k];
@@ -758,8 +848,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                 const int steps = (K - g + 3) >> 2;          // rows g + 4 i < K
                 const f2* src = own_base + j * OLD + koff + g;
                 const f2* dsp = disp_base + j * LDF + g;
-                float* dst = p.out + (b * static_cast<long long>(ncols) + tr + j_o) * C + g_o;
-                float* dsti = dst + K;
+                // (uniform 64-bit base + a 32-bit lane offset: no per-lane 64-bit address pair to keep or spill)
+                float* gbase = p.out + (b * static_cast<long long>(ncols) + tr) * C;
+                int g_g = g_o, j_g = j_o;                    // opaque per GROUP: otherwise the two addresses are computed per
+                asm volatile("" : "+v"(g_g), "+v"(j_g));     // chunk, held through the transform and spilled
+                const int loff = j_g * C + g_g;
+                float* dst = gbase + loff;
+                float* dsti = gbase + (loff + K);
                 for (int i = 0; i < steps; ++i) {
                     f2 v = src[4 * i];
                     if (wdirty) v += dsp[4 * i];

@@ -145,6 +145,8 @@ struct hssfsst_plan {
     int nwin = 0, R = 0, nf = 0, klo = 0, K = 0, mode = 0;
     double fs = 0.0;
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
+    float r2scale = 0.0f;         // 4 nwin max |(w + i dw') / 2|^2: error-bound scale of the rounding-tie path
+    double* d_wtab = nullptr;     // float64 {w, dw' in bin units}[nwin], then {cos, sin}(2 pi m / nwin)[nwin]: rounding-tie path
     float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
     int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
@@ -281,6 +283,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     hssfsst::Core128Params cp{};
     cp.xstride = xstride;
     cp.x = dx; cp.out = dout; cp.partials = partials; cp.atab = pl->d_atab;
+    cp.wtab = pl->d_wtab; cp.twtab = pl->d_wtab + 2 * pl->nwin; cp.r2scale = pl->r2scale;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = static_cast<int>(batch);
     cp.col0 = col0; cp.ncols = ncols;
     cp.reg = hssfsst::core128_regions((ncols + 15) / 16);
@@ -425,6 +428,24 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     if (e != hipSuccess) { delete p; return fail(HSSFSST_ENOMEM, "plan_create: hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(p->d_ctab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(p->d_ctab); delete p; return fail(HSSFSST_EHIP, "plan_create: hipMemcpy: %s", hipGetErrorString(e)); }
+    {   // float64 tables of the rounding-tie path: the window pair and the twiddles
+        std::vector<double> wt(static_cast<size_t>(4) * nwin);
+        double cmax2 = 0.0;
+        for (int i = 0; i < nwin; ++i) cmax2 = std::fmax(cmax2, 0.25 * (window[i] * window[i] + dwb[i] * dwb[i]));
+        p->r2scale = static_cast<float>(4.0 * nwin * cmax2);
+        for (int i = 0; i < nwin; ++i) {
+            wt[2 * i] = window[i]; wt[2 * i + 1] = dwb[i];
+            const double ang = 2.0 * M_PI * static_cast<double>(i) / static_cast<double>(nwin);
+            wt[2 * nwin + 2 * i] = std::cos(ang); wt[2 * nwin + 2 * i + 1] = std::sin(ang);
+        }
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_wtab), wt.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(p->d_wtab, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (p->d_wtab) (void)hipFree(p->d_wtab);
+            (void)hipFree(p->d_ctab); delete p;
+            return fail(HSSFSST_EHIP, "plan_create: float64 table upload: %s", hipGetErrorString(e));
+        }
+    }
     const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
     static const bool mfma_long = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);   // A/B: nwin 256 / 512 on the generic kernel
     bool use_mfma = (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !(force && force[0] == '1');
@@ -468,7 +489,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
         if (e == hipSuccess) e = hipMemcpy(p->d_atab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             if (p->d_atab) (void)hipFree(p->d_atab);
-            (void)hipFree(p->d_ctab); delete p;
+            (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;
             return fail(HSSFSST_EHIP, "plan_create: A-table upload: %s", hipGetErrorString(e));
         }
     }
@@ -481,6 +502,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (!p) return 0;
     DeviceGuard device_guard_(p->device);
     if (p->d_ctab) (void)hipFree(p->d_ctab);
+    if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_status) (void)hipFree(p->d_status);
@@ -655,6 +677,7 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         hssfsst::CoreParams cp;
         cp.x = cx; cp.out = cout; cp.partials = p->d_partials ? p->d_partials + c0 * nblk * hssfsst::kPartFloats : nullptr; cp.ctab = p->d_ctab;
         cp.n = n; cp.klo = p->klo; cp.K = p->K; cp.mode = p->mode; cp.nblk = nblk; cp.col0 = col0; cp.ncols = ncols; cp.xstride = x_stride;
+        cp.wtab = p->d_wtab; cp.twtab = p->d_wtab + 2 * p->nwin; cp.r2scale = p->r2scale;
         const long long cblocks = static_cast<long long>(cb) * nblk;
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }

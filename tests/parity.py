@@ -2,17 +2,19 @@
 
 Per signal:  max|out - ref| <= TOL * max|ref|  and  ||out - ref||_2 <= TOL * ||ref||_2, evaluated on
 the time columns that are NOT rounding-fragile.  A column is fragile when some source cell's
-reassignment coordinate lies within FRAG_EPS of a rounding tie in the fp64 oracle: there an fp32
-core may legitimately send that cell to the neighbouring row (SURVEY section 7 "discontinuous
-rounding").  Fragile columns are counted and bounded, never silently dropped: the gate also fails
+reassignment coordinate lies within FRAG_EPS of a rounding tie in the fp64 oracle (SURVEY section 7
+"discontinuous rounding"; round 1 needed 1e-3 here and budgets of 3-25 % of the columns, since round 2
+the GPU path resolves such cells in float64 itself).  Fragile columns are counted and bounded, never silently dropped: the gate also fails
 if they exceed FRAG_BUDGET of all columns, and inside them the error must still be explainable by
 a moved cell (|err| bounded by twice the signal's largest feature).
 """
 import numpy as np
 
 TOL = 1e-4          # the tolerance north_star states (fp32, relative to the signal's max feature)
-FRAG_EPS = 1e-3     # distance from a rounding tie below which a column is "fragile"
-FRAG_BUDGET = 0.03
+FRAG_EPS = 1e-7     # distance from a rounding tie below which a column is "fragile": the kernels decide every
+                    # rounding that float32 cannot call in float64 (fsst_mfma128.hpp "Rounding ties"), so only ties
+                    # at float64 resolution remain (a different summation order may round them the other way)
+FRAG_BUDGET = 0.001
 
 
 def check(out, ref, halfdist, time_axis, tol=TOL, frag_eps=FRAG_EPS, frag_budget=FRAG_BUDGET, what=""):

@@ -98,8 +98,8 @@ def test_other_windows(oracle_mod, name, fs, band):
          "hamming32": get_window("hamming", 32, fftbins=False),
          "kaiser05_512": get_window(("kaiser", 0.5), 512, fftbins=False)}[name]
     X = synth.noise_windows(2, 900, seed=9)
-    _run_and_check(oracle_mod, X, fs, w, band, stack=True, what=name, frag_budget=0.25)
-    _run_and_check(oracle_mod, X, fs, w, band, what=name + "/raw", frag_budget=0.25)
+    _run_and_check(oracle_mod, X, fs, w, band, stack=True, what=name)
+    _run_and_check(oracle_mod, X, fs, w, band, what=name + "/raw")
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 127, 128, 129, 191, 300, 2001])
@@ -170,11 +170,8 @@ def test_golden_fixtures():
         assert got.dtype == y.dtype, tag
         scale = np.abs(y).max()
         err = np.abs(got - y)
-        # golden data carries no tie-distance vector: allow <= 0.5 % of columns to exceed (flips)
-        tax = 1 if np.iscomplexobj(y) else 0
-        colerr = np.moveaxis(err, tax, 0).reshape(err.shape[tax], -1).max(axis=1)
-        bad = (colerr > parity.TOL * scale).sum()
-        assert bad <= max(1, 0.005 * colerr.size), f"{tag}: {bad} columns off, max {colerr.max():.3e} vs scale {scale:.3e}"
+        # every column within the gate: no allowance for rounding flips (the kernels resolve them in float64)
+        assert err.max() <= parity.TOL * scale, f"{tag}: max err {err.max():.3e} vs scale {scale:.3e}"
 
 
 def test_input_shapes_and_dtypes(oracle_mod):
@@ -347,8 +344,8 @@ def test_kernel_variants_agree(tmp_path):
         g = paths["generic"][k]
         scale = np.abs(ref[k]).max()
         colerr = np.abs(g - ref[k]).reshape(ref[k].shape[0], -1)
-        # different kernels => different fp32 rounding; allow isolated tie flips (<= 0.1 % of cells)
-        assert (colerr > parity.TOL * scale).mean() < 1e-3, ("generic", k, colerr.max(), scale)
+        # different kernels => different fp32 rounding of the values, but the same rounding decisions
+        assert colerr.max() <= parity.TOL * scale, ("generic", k, colerr.max(), scale)
 
 
 _SHARE_CHILD = r'''
@@ -428,7 +425,7 @@ def test_streaming_matches_offline(oracle_mod):
         s, f, t, hd = oracle_mod.fsst(x[c], fs, w, return_halfdist=True)
         klo, K = oracle_mod.band(N, fs, *BAND)
         ref = np.concatenate([s[klo:klo + K].real.T, s[klo:klo + K].imag.T], axis=1).astype(np.float32)
-        parity.check(off[c], ref, hd, 0, what=f"stream ch{c}", frag_budget=0.1)
+        parity.check(off[c], ref, hd, 0, what=f"stream ch{c}")
     # running normalisation == z-score with the statistics of everything seen so far
     st2 = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True)
     seen = []
@@ -559,3 +556,26 @@ def test_fused_zscore_bit_identical_to_two_kernel_path(n, batch):
         subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HSSFSST_NO_FUSED="1"), timeout=600)
         ref = np.load(os.path.join(td, "ref.npy"))
     assert np.array_equal(got, ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("band", [None, (0, 20), (0, 7), BAND])
+@pytest.mark.parametrize("n,batch", [(2000, 3), (2000, 512)])
+def test_dc_offset_statistics(oracle_mod, band, n, batch):
+    """A recording with a DC offset 50x its spread, bands that contain row 0: mean^2 >> variance in the real block, the
+    case in which a single-pass float32 sum x, sum x^2 loses the variance (round 1's statistics did).  The partials are
+    pivoted sums (fsst_kernels.hpp "Statistics"), so the z-score still meets the 1e-4 gate -- on the two-kernel path
+    (batch 3) and on the fused kernel (batch 512)."""
+    X = (synth.noise_windows(batch, n, seed=31) + 50.0).astype(np.float32)
+    if band == (0, 7):
+        # only the DC row: its imaginary part is identically 0 (NaN block, as the wrapper gives for a constant block)
+        got = FSST(1000, KAISER, truncate_freq=band, stack=True).batch(torch.from_numpy(X).cuda()).cpu().numpy()
+        ref = oracle_mod.features(X[:4], 1000, KAISER, band, "stack")
+        assert np.isnan(got[..., 1]).all()
+        assert np.abs(got[:4, :, 0] - ref[..., 0]).max() <= parity.TOL * np.abs(ref[..., 0]).max()
+        return
+    tf = FSST(1000, KAISER, truncate_freq=band, stack=True)
+    got = tf.batch(torch.from_numpy(X).cuda()).cpu().numpy()
+    tf.check()
+    ref, hd = oracle_mod.features(X[:4], 1000, KAISER, band, "stack", nthreads=4, return_halfdist=True)
+    for b in range(4):
+        parity.check(got[b], ref[b], hd[b], 0, what=f"dc offset band={band} [{b}]")

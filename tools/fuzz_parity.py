@@ -1,11 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random (batch, n, band, mode, window, nwin, input scale) against the fp64
 oracle with the gate of tests/parity.py.  usage: fuzz_parity.py [cases=150] [seed=1]
-Outcomes are classified: errors (exceptions) and gate failures with the near-rectangular Kaiser(0.5) window are real
-failures (exit 1); with heavy-reassignment windows (Hann, Hamming, Kaiser beta 6) two things are expected and only
-counted: more rounding-fragile columns than the budget (at nwin = 512 a column has 257 sources, each within 1e-3 of a
-rounding tie with probability ~1e-3) and isolated fp32-vs-fp64 rounding flips in columns the oracle calls robust
-(profiles/r01_flip_census.txt)."""
+Every exception and every gate failure is a failure (exit 1), heavy-reassignment windows (Hann, Hamming, Kaiser beta 6)
+included: round 1 had to exempt them (rounding flips of small far-moving cells, profiles/r01_flip_census.txt); since round 2
+the kernels decide such roundings in float64 (fsst_mfma128.hpp "Rounding ties")."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,19 +45,13 @@ for case in range(ncases):
         for b in range(batch):
             if mode == "stack" and not np.isfinite(ref[b]).all():
                 continue                                  # degenerate statistics (constant block): reference gives NaN/inf too
-            r = parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=desc, frag_budget=0.35 if heavy else 0.05)
+            r = parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=desc, )
             worst = max(worst, r["rel"])
     except AssertionError as e:
         msg = str(e)
-        if heavy and "fragile columns exceed the budget" in msg:
-            heavy_budget += 1
-        elif heavy and ("max err" in msg or "rel L2" in msg):
-            heavy_flip += 1; print("flip (heavy window)", desc, "\n    ", msg[:200], flush=True)
-        else:
-            fails += 1; print("FAIL", desc, "\n    ", msg[:300], flush=True)
+        fails += 1; print("FAIL" + (" (heavy window)" if heavy else ""), desc, "\n    ", msg[:300], flush=True)
     except Exception as e:                                # noqa: BLE001
         fails += 1; print("ERROR", desc, "\n    ", type(e).__name__, str(e)[:300], flush=True)
-print(f"{ncases} cases drawn, {ran} run: {fails} failures; heavy-window cases over the fragile-column budget {heavy_budget}, "
-      f"with a rounding flip in a robust column {heavy_flip}; worst robust rel err of the passing signals {worst:.2e}; "
-      f"{time.time() - t_start:.0f} s")
+print(f"{ncases} cases drawn, {ran} run: {fails} failures; worst rel err of the passing signals {worst:.2e}; "
+      f"frag_eps {parity.FRAG_EPS:g}, frag budget {parity.FRAG_BUDGET:g}; {time.time() - t_start:.0f} s")
 sys.exit(1 if fails else 0)
