@@ -17,6 +17,7 @@
 
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
+#include "fsst_dft.hpp"
 #include "fourier_resample.hpp"
 #include <cstdlib>
 
@@ -145,6 +146,8 @@ struct hssfsst_plan {
     int nwin = 0, R = 0, nf = 0, klo = 0, K = 0, mode = 0;
     double fs = 0.0;
     float* d_ctab = nullptr;      // generic kernel: class-folded scalar tables
+    float* d_dtab = nullptr;      // any-length kernel (fsst_dft.hpp): A operand [source block][k-step][64 lanes]
+    int dft = 0;                  // 1: this plan runs the any-length kernel
     float r2scale = 0.0f;         // 4 nwin max |(w + i dw') / 2|^2: error-bound scale of the rounding-tie path
     double* d_wtab = nullptr;     // float64 {w, dw' in bin units}[nwin], then {cos, sin}(2 pi m / nwin)[nwin]: rounding-tie path
     float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
@@ -377,8 +380,9 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     *out = nullptr;
     if (!window || nwin < 1 || !(fs > 0.0) || mode < 0 || mode > HSSFSST_MODE_STACK_UNNORM)
         return fail(HSSFSST_EINVAL, "plan_create: bad argument (nwin=%d fs=%g mode=%d)", nwin, fs, mode);
-    if (nwin != 32 && nwin != 64 && nwin != 128 && nwin != 256 && nwin != 512)
-        return fail(HSSFSST_EUNSUPPORTED, "plan_create: window length %d not in {32,64,128,256,512}", nwin);
+    if (nwin > 65535) return fail(HSSFSST_EUNSUPPORTED, "plan_create: window length %d exceeds 65535", nwin);
+    static const bool force_dft = std::getenv("HSSFSST_FORCE_DFT") != nullptr;       // cross-check: every length on the any-length kernel
+    const bool radix_len = nwin == 32 || nwin == 64 || nwin == 128 || nwin == 256 || nwin == 512;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -401,9 +405,11 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     if (rc != 0) { delete p; return fail(rc, "plan_create: singular spline system"); }
     for (int i = 0; i < nwin; ++i) dwb[i] *= static_cast<double>(nwin) / (2.0 * M_PI);
 
-    const int R = p->R;
+    p->dft = (!radix_len || force_dft) ? 1 : 0;
+    const int R = p->dft ? 2 : p->R;                      // (the class-folded tables below are only read by the radix kernels)
     const int ncls = R / 2 + 1;
     std::vector<float> tab(static_cast<size_t>(ncls) * 32 * 4 * R, 0.0f);
+    if (!p->dft)
     for (int r = 0; r < ncls; ++r) {
         const bool packed = (r == 0) || (2 * r == R);
         for (int n = 0; n < 32; ++n) {
@@ -448,7 +454,39 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     }
     const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
     static const bool mfma_long = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);   // A/B: nwin 256 / 512 on the generic kernel
-    bool use_mfma = (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !(force && force[0] == '1');
+    bool use_mfma = !p->dft && (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !(force && force[0] == '1');
+    if (p->dft) {
+        // A[i][k] of v_mfma_f32_16x16x4_f32 for source block blk, k-step ks: lane l holds row i = l & 15, k = l >> 4.
+        // Row i: source k' = 4 blk + (i >> 2), component i & 3 of {V.re, V.im, Vd'.re, Vd'.im}; tap n = 4 ks + k:
+        //   V  [k'] = sum_n x[t + n] w  [n] e^{-2 pi i k' (n + m) / N},  m = floor(N / 2) (the modified-STFT phase, step 5)
+        //   Vd'[k'] = sum_n x[t + n] dw'[n] e^{-2 pi i k' (n + m) / N}
+        // (k' (n + m) is reduced modulo N in integers before the angle is formed)
+        const int nf = p->nf, nk4 = (nwin + 3) / 4, nblk4 = (nf + 3) / 4, m = nwin / 2;
+        const size_t per_wave = static_cast<size_t>(hssfsst::dft_wave_lds_floats(nk4, p->K > 0 ? p->K : 1)) * sizeof(float);
+        if (per_wave > static_cast<size_t>(kMaxLdsBytes)) {
+            (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;
+            return fail(HSSFSST_EUNSUPPORTED, "plan_create: window length %d with %d kept rows needs %zu B of LDS per wave (> 160 KiB): "
+                                              "narrow the band", nwin, p->K, per_wave);
+        }
+        std::vector<float> dt(static_cast<size_t>(nblk4) * nk4 * 64, 0.0f);
+        for (int blk = 0; blk < nblk4; ++blk)
+            for (int ks = 0; ks < nk4; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, n = 4 * ks + (l >> 4), kp = 4 * blk + (i >> 2), sub = i & 3;
+                    if (kp >= nf || n >= nwin) continue;
+                    const long long red = (static_cast<long long>(kp) * (n + m)) % nwin;
+                    const double ang = -2.0 * M_PI * static_cast<double>(red) / static_cast<double>(nwin);
+                    const double amp = (sub < 2) ? window[n] : dwb[n];
+                    dt[(static_cast<size_t>(blk) * nk4 + ks) * 64 + l] = static_cast<float>(amp * ((sub & 1) ? std::sin(ang) : std::cos(ang)));
+                }
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_dtab), dt.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->d_dtab, dt.data(), dt.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (p->d_dtab) (void)hipFree(p->d_dtab);
+            (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;
+            return fail(HSSFSST_EHIP, "plan_create: DFT table upload (%zu B): %s", dt.size() * sizeof(float), hipGetErrorString(e));
+        }
+    }
     const int nt0 = (nwin == 512) ? 32 : 16, rq0 = nwin / nt0;
     if (use_mfma) {                                      // enough wave regions of this band must fit beside the A table
         const int min_waves = (nwin == 512) ? 2 : 4;
@@ -503,6 +541,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     DeviceGuard device_guard_(p->device);
     if (p->d_ctab) (void)hipFree(p->d_ctab);
     if (p->d_wtab) (void)hipFree(p->d_wtab);
+    if (p->d_dtab) (void)hipFree(p->d_dtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_status) (void)hipFree(p->d_status);
@@ -604,7 +643,7 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
     // statistics partials per signal: one per 16-frame group (MFMA kernel) / per 64-frame tile (generic kernel)
-    const int fpp = use128 ? 16 : kTile;
+    const int fpp = (use128 || p->dft) ? 16 : kTile;
     const int nblk = (ncols + fpp - 1) / fpp;
     const long long nblocks = static_cast<long long>(batch) * nblk;
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
@@ -683,7 +722,24 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         bool did_fuse = false;
         static const bool no_fused = std::getenv("HSSFSST_NO_FUSED") != nullptr;        // A/B and bit-equality tests
-        if (use128) {
+        if (p->dft) {
+            hssfsst::DftParams dp{};
+            dp.x = cx; dp.out = cout; dp.partials = cp.partials; dp.atab = p->d_dtab;
+            dp.wtab = p->d_wtab; dp.twtab = p->d_wtab + 2 * p->nwin;
+            dp.n = n; dp.nwin = p->nwin; dp.nf = p->nf; dp.klo = p->klo; dp.K = p->K; dp.mode = p->mode; dp.col0 = col0; dp.ncols = ncols;
+            dp.nk4 = (p->nwin + 3) / 4; dp.nblk4 = (p->nf + 3) / 4;
+            dp.nitems = static_cast<long long>(cb) * nblk; dp.xstride = x_stride; dp.r2scale = p->r2scale;
+            const size_t per_wave = static_cast<size_t>(hssfsst::dft_wave_lds_floats(dp.nk4, p->K)) * sizeof(float);
+            int waves = static_cast<int>(static_cast<size_t>(kMaxLdsBytes) / per_wave);
+            if (waves > 8) waves = 8;
+            if (waves < 1) return fail(HSSFSST_EUNSUPPORTED, "exec: LDS request %zu B per wave exceeds 160 KiB", per_wave);
+            static std::atomic<unsigned long long> lds_ok{0};
+            if ((rc = allow_full_lds(hssfsst::fsst_dft_kernel, p->device, lds_ok)) != 0) return rc;
+            long long blocks = (dp.nitems + waves - 1) / waves;
+            if (blocks > 256 * 64) blocks = 256 * 64;                       // grid-stride beyond that
+            hipLaunchKernelGGL(hssfsst::fsst_dft_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64 * waves), per_wave * waves, st, dp);
+            rc = (hipGetLastError() == hipSuccess) ? 0 : fail(HSSFSST_EHIP, "exec: fsst_dft_kernel launch failed");
+        } else if (use128) {
             rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st, !no_fused && !piped, &did_fuse);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;

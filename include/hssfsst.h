@@ -33,7 +33,7 @@ extern "C" {
 #define HSSFSST_OK 0
 #define HSSFSST_EINVAL (-1)    /* bad argument (NULL, non-positive size, unknown mode ...)        */
 #define HSSFSST_ENODEVICE (-2) /* no usable HIP device / runtime                                  */
-#define HSSFSST_EUNSUPPORTED (-3) /* window length not in {32,64,128,256,512}                     */
+#define HSSFSST_EUNSUPPORTED (-3) /* configuration beyond the kernels' LDS budget (huge window x wide band)  */
 #define HSSFSST_ENOMEM (-4)    /* host or device allocation failed                                */
 #define HSSFSST_EHIP (-5)      /* a HIP call failed (message in hssfsst_last_error)               */
 
@@ -49,7 +49,9 @@ typedef struct hssfsst_plan hssfsst_plan;
  * (fs, window): derivative window (not-a-knot spline), class-folded twiddle tables, the kept band
  * of _truncate_frequencies (synchrosqueeze.py:91-111; inclusive bounds compared in float32).
  *   device     HIP device ordinal (>= 0)
- *   window     nwin doubles (the analysis window; nfft = nwin); nwin in {32,64,128,256,512}
+ *   window     nwin doubles (the analysis window; nfft = nwin).  Any length, odd ones included, as the reference
+ *              (synchrosqueeze.py:48): 32 / 64 / 128 / 256 / 512 run the radix kernels, every other length the
+ *              any-length kernel (windowed DFT on the fp32 matrix pipe, csrc/fsst_dft.hpp)
  *   has_band   0: keep all nwin/2+1 rows; 1: keep rows with f_lo <= k*fs/nwin <= f_hi
  *   mode       HSSFSST_MODE_* */
 int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* window, double fs,
