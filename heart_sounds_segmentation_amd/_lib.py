@@ -21,6 +21,28 @@ E_INVAL, E_NODEVICE, E_UNSUPPORTED, E_NOMEM, E_HIP = -1, -2, -3, -4, -5
 
 _lock = threading.Lock()
 _lib = None
+hip_owner_pid = None     # pid of the process in which this package first touched HIP (inherited by forked children)
+
+
+def guard_fork() -> None:
+    """HIP cannot be used in a child forked AFTER the parent initialised it (the reference forks DataLoader workers,
+    /root/reference/main.py:202-218).  Creating the plan lazily in the worker is fine -- that is the supported pattern;
+    a worker forked from a parent that already ran a transform gets a RuntimeError here (the exception the reference's
+    dataset catches, hss/datasets/heart_sounds.py:183) instead of undefined behaviour inside the driver."""
+    global hip_owner_pid
+    pid = os.getpid()
+    if hip_owner_pid is not None and hip_owner_pid != pid:
+        raise RuntimeError("FSST: the HIP runtime was initialised in the parent process before this worker was forked; "
+                           "create / first use the transform inside the worker (lazy plan), or start workers with "
+                           "multiprocessing_context='spawn'")
+    try:
+        import torch
+        if torch.cuda._is_in_bad_fork():
+            raise RuntimeError("FSST: torch initialised the GPU in the parent process before this worker was forked; "
+                               "use multiprocessing_context='spawn' or touch the GPU only inside the workers")
+    except (ImportError, AttributeError):
+        pass
+    hip_owner_pid = pid
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -24,6 +24,7 @@ class _Plan:
     """Owner of one ``hssfsst_plan*`` (created lazily in the calling process: fork-safe)."""
 
     def __init__(self, device_index: int, window: np.ndarray, fs: float, band, mode: int):
+        _lib.guard_fork()
         L = _lib.lib()
         self._L = L
         self.handle = ctypes.c_void_p()
@@ -91,6 +92,7 @@ class FSST:
         return _lib.MODE_RAW
 
     def _device_index(self, like: Optional[torch.Tensor] = None) -> int:
+        _lib.guard_fork()
         if like is not None and like.is_cuda:
             return like.device.index if like.device.index is not None else torch.cuda.current_device()
         if not torch.cuda.is_available():

@@ -622,3 +622,69 @@ def test_any_length_kernel_agrees_with_radix_kernels():
     for key, w in (("a", KAISER), ("b", get_window("hann", 64, fftbins=False))):
         ref = FSST(1000, w).batch(Xd).cpu().numpy()
         assert np.abs(d[key] - ref).max() <= parity.TOL * np.abs(ref).max(), key
+
+
+def test_known_answers_hip():
+    """The closed-form answers of tests/known_answers.py (no oracle involved) on the HIP path, float32 tolerances:
+    impulse (padding, orientation, phase factor), constant (everything lands in row 0), off-bin tone, linear chirp
+    ridge, exact shift covariance and homogeneity, an odd window through the any-length kernel."""
+    from tests import known_answers as ka
+    from heart_sounds_segmentation_amd import ssq
+
+    def f(x, fs, w):
+        return ssq.fsst(np.asarray(x, dtype=np.float32), fs, w)[0]
+    for case in ka.ALL:
+        print(case.__name__, case(f))
+
+
+def test_ssq_shim_matches_oracle(oracle_mod):
+    """ssq.fsst(x, fs, window) -> (s, f, t): the call the reference makes (synchrosqueeze.py:48), all three outputs."""
+    from heart_sounds_segmentation_amd import ssq
+    x = synth.pcg_windows(1, 1500, seed=8)[0]
+    for xin in (x, x.astype(np.float64), x.reshape(-1, 1)):
+        s, f, t = ssq.fsst(xin, 1000, KAISER)
+        sr, fr, tr, hd = oracle_mod.fsst(x.astype(np.float64), 1000.0, KAISER, return_halfdist=True)
+        assert s.shape == (65, 1500) and np.iscomplexobj(s) and np.array_equal(f, fr) and np.array_equal(t, tr)
+        parity.check(s.astype(np.complex64), sr.astype(np.complex64), hd, 1, what="ssq shim")
+
+
+_FORK_CHILD = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from torch.utils.data import DataLoader, Dataset
+from heart_sounds_segmentation_amd import FSST, synth
+mode = sys.argv[1]
+tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True)     # no plan yet: created on first use
+recs = [torch.from_numpy(synth.recording(6000, seed=s)) for s in range(4)]
+
+class Lazy(Dataset):                      # the reference's in_memory=False path (hss/datasets/heart_sounds.py:175-184)
+    def __len__(self): return len(recs)
+    def __getitem__(self, i):
+        try:
+            return tf(recs[i])
+        except RuntimeError as e:
+            return torch.full((1,), float("nan"))
+
+if mode == "parent_first":
+    tf(recs[0])                           # the parent initialises HIP, THEN forks workers
+dl = DataLoader(Lazy(), batch_size=None, num_workers=2, multiprocessing_context="fork")
+outs = [y for y in dl]
+if mode == "lazy":
+    ref = [tf(r) for r in recs]           # the parent touches the GPU only now
+    ok = all(o.shape == (6000, 44) and torch.equal(o, r) for o, r in zip(outs, ref))
+    print("LAZY_OK" if ok else "LAZY_BAD")
+else:
+    print("REFUSED" if all(o.numel() == 1 and torch.isnan(o).all() for o in outs) else "NOT_REFUSED")
+'''
+
+
+@pytest.mark.parametrize("mode,want", [("lazy", "LAZY_OK"), ("parent_first", "REFUSED")])
+def test_fork_workers(mode, want):
+    """main.py:202-218 forks DataLoader workers.  Supported pattern: the transform object is built in the parent, its
+    plan (and the HIP context) is created lazily inside each forked worker -- results equal the parent's own.  A parent
+    that already used the GPU before forking gets a clean RuntimeError in the workers (the exception the reference's
+    dataset catches), not a hang."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FORK_CHILD, mode], cwd=root, capture_output=True, text=True, timeout=300)
+    assert want in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
