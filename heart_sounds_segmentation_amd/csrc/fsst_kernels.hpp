@@ -166,8 +166,8 @@ struct Scatter {
 // wherever it lands and is treated as staying.  Only when some lane of the wave has a displaced
 // cell does the wave run the exact rounding path for those lanes.
 constexpr float kTieMarginG = 1.0f / 64.0f;      // (== kTieMargin, kTieErr2, kTieFloor2 of fsst_mfma128.hpp, where the
-constexpr float kTieErr2G = 1.6e-13f;            //  error model behind them is described)
-constexpr float kTieFloor2G = 1.0e-10f;
+constexpr float kTieErr2G = 1.0e-12f;            //  error model behind them is described)
+constexpr float kTieFloor2G = 1.0e-12f;
 
 template <int NWIN, int LD>
 __device__ __forceinline__ void scatter_source(const Scatter<LD>& sc, float kp, int kpi, float sgn,

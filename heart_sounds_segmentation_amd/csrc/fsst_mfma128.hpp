@@ -251,18 +251,22 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // bins (Hann-, Blackman-, Kaiser(beta >> 1)-class windows) that is up to ~1e-2 bins, enough to put the cell into the
 // neighbouring row of the float64 reference.  The kernel therefore carries an error bound with every displaced cell:
 // with R^2 = 4 nwin max|c|^2 sum x^2 over the staged tile (Parseval: an upper bound of sum |Z|^2 of every frame of the tile,
-// c = (w + i dw') / 2) the coordinate is good to about  tau = kTieErr (1 + |shift|) R / |V|.  A displaced cell whose float32
+// c = (w + i dw') / 2) the coordinate is good to about  tau = 1e-6 (1 + |shift|) R / |V|.  A displaced cell whose float32
 // coordinate lies within tau of a half-integer is NOT moved on the spot: it goes to a per-wave queue in LDS (frame, bin,
 // value) and, once the group's spectra are done and their registers free, the whole wave recomputes that one bin of V
 // and Vd' by a float64 DFT of the frame (two taps per lane for nwin = 128, window and twiddle tables in float64 from
-// HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below kTieFloor R are left to float32: they
-// cannot change a feature by 1e-5 of the frame's spectrum norm wherever they land.  Large cells have tau ~ 1e-6 and are
+// HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below 1e-6 R are left to float32: they
+// cannot change a feature by 1e-4 of the largest feature wherever they land.  Large cells have tau ~ 1e-6 and are
 // practically never queued; the queue holds the small far-moving cells that float32 cannot place.
 constexpr int kTieQueue = 32;                // entries per wave and 16-frame group; overflow falls back to float32
 constexpr int kTieWords = 4 + 3 * kTieQueue; // [0] count, [4 + 3 e ..] = {bin | frame << 16, V.re, V.im}
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
-constexpr float kTieErr2 = 1.6e-13f;         // (4e-7)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2
-constexpr float kTieFloor2 = 1.0e-10f;       // (1e-5)^2: cells with |V|^2 below this times R^2 stay with float32
+constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
+                                             // random configurations 1.4-1.8x over the gate: tools/fuzz_parity.py 1000 3)
+constexpr float kTieFloor2 = 1.0e-12f;       // (1e-6)^2: cells with |V|^2 below this times R^2 stay with float32.  R over-
+                                             // estimates the frame's spectrum norm by up to ~5x and that norm is at most
+                                             // sqrt(nwin) times the largest bin, so 1e-6 R is < 1e-4 of the largest feature
+                                             // (1e-5 R was not: 3 of 2000 random narrow-band configurations failed the gate)
 
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8, int nt = 16)
 {
