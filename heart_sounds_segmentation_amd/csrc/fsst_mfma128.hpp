@@ -750,13 +750,17 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
 #endif
         });
         wave_sync();
-        if (__builtin_amdgcn_readfirstlane(tq[0]) != 0) {    // (rare) cells whose rounding float32 cannot decide
+        // one LDS round trip for both per-group flags (dirty displaced plane, queued rounding ties)
+        int f_dirty = flag[0];
+        const int f_ties = tq[0];
+        if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
             resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, p.wtab, p.twtab, lane_o);
             wave_sync();
+            f_dirty = flag[0];
         }
 
         // ---- epilogue for these 16 frames: element f -> (frame jj, kept row k)
-        const bool wdirty = __builtin_amdgcn_readfirstlane(*flag) != 0;
+        const bool wdirty = __builtin_amdgcn_readfirstlane(f_dirty) != 0;
         const int nvalid = min(16, cend - tg);
         const int koff = klo - RQ * s0;
         const int gidx = grp0 + sub + grp;                   // group index in the signal = statistics partial slot

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 101
+#define HSSFSST_VERSION 200
 
 /* status codes */
 #define HSSFSST_OK 0

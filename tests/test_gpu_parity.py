@@ -40,7 +40,7 @@ def _run_and_check(oracle_mod, X, fs, window, band, abs_=False, stack=False, wha
 
 def test_library_loaded_and_device():
     L = _lib.lib()
-    assert L.hssfsst_version() == 101
+    assert L.hssfsst_version() == 200
     assert L.hssfsst_device_count() >= 1
 
 
