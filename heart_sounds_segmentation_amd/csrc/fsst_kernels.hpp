@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
 #endif
 #pragma unroll HSS_NORM_UNROLL
             for (int i = i0 + tid; i < i1; i += 256) {
-                float4 v = b4[i];
+                float4 v = b4[i];                        // (streaming load / store hints measured here: 0.147 vs 0.119 ms, worse)
                 int c1 = c + 1, c2 = c + 2, c3 = c + 3;
                 if (rowwrap) {
                     if (c1 >= C) c1 -= C;
