@@ -605,6 +605,13 @@ int hssfsst_plan_timing(hssfsst_plan* p, float ms_sum[2], int* nexec)
     HIP_TRY(hipEventSynchronize(p->ev[p->ev_used - 1]));
     size_t i = 0;
     for (int nc : p->ev_chunks) {
+        if (nc < 0) {                                    // fused exec: (before, after) only
+            float a = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&a, p->ev[i], p->ev[i + 1]));
+            ms_sum[0] += a;
+            i += 2;
+            continue;
+        }
         float core = 0.0f, total = 0.0f;
         for (int c = 0; c < nc; ++c) {
             float a = 0.0f;
@@ -790,10 +797,14 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         HIP_TRY(hipStreamWaitEvent(st, p->sync_ev[nchunks], 0));
     }
     if (p->timing) {
-        hipEvent_t evt = nullptr;
-        if ((rc = next_event(&evt)) != 0) return rc;
-        HIP_TRY(hipEventRecord(evt, st));
-        p->ev_chunks.push_back(timed_chunks);
+        if (p->last_fused && timed_chunks == 1) {
+            p->ev_chunks.push_back(-1);                  // one kernel did everything: its two events are the whole exec
+        } else {
+            hipEvent_t evt = nullptr;
+            if ((rc = next_event(&evt)) != 0) return rc;
+            HIP_TRY(hipEventRecord(evt, st));
+            p->ev_chunks.push_back(timed_chunks);
+        }
     }
     if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
