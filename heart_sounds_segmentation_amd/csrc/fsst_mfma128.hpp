@@ -314,7 +314,11 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
     const float a = static_cast<float>(kpi) + shift;
     const float fr = a - floorf(a) - 0.5f, s1 = 1.0f + fabsf(shift);
+#ifdef HSS_NO_TIES                                       // development: cost of the tie path (tools/ab_bench.py)
+    if (false) {
+#else
     if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
+#endif
         const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (slot < kTieQueue) {
             tq[4 + 3 * slot] = kpi | (j << 16);
@@ -393,7 +397,11 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
     }
     // (the threshold sits kTieMargin below 1/2 so that a cell whose |shift| is within the margin of 1/2 -- a rounding
     //  tie as well -- reaches the rare path and its float64 decision)
+#ifdef HSS_NO_TIES
+    constexpr float kStay = 0.5f;
+#else
     constexpr float kStay = 0.5f - kTieMargin;
+#endif
     const bool ma = fabsf(dna.y) >= kStay * dna.x, mb = fabsf(dnb.y) >= kStay * dnb.x;
     if (ma | mb) {                                      // skipped when no lane moved (execz)
         if (ma) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2);

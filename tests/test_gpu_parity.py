@@ -688,3 +688,25 @@ def test_fork_workers(mode, want):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _FORK_CHILD, mode], cwd=root, capture_output=True, text=True, timeout=300)
     assert want in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("batch", [3, 256])
+def test_stack_over_a_column_range(batch):
+    """hssfsst_exec_cols in STACK mode (statistics over the requested columns only), two-kernel path (batch 3) and fused
+    kernel (batch 256): equals the z-score, computed in float64 by torch, of the un-normalised columns."""
+    X = torch.from_numpy(synth.pcg_windows(batch, 2000, seed=77)).cuda()
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    cols = (160, 1696)                                     # 106 groups: inside the fused kernel's range
+    got = tf._run(X, cols=cols)
+    assert tf.check() == (batch >= 256) or torch.cuda.get_device_properties(0).multi_processor_count != 256
+    raw = tf.unnormalized(X, cols=cols).double()
+    assert got.shape == raw.shape == (batch, 1696, 44)
+    for h in (slice(0, 22), slice(22, 44)):
+        blk = raw[..., h]
+        m = blk.mean(dim=(1, 2), keepdim=True)
+        sd = blk.flatten(1).std(dim=1, unbiased=True)[:, None, None]
+        want = ((blk - m) / sd).float()
+        assert (got[..., h] - want).abs().max() <= 2e-5 * want.abs().max()
+    full = tf.batch(X)                                     # and the columns themselves are the full transform's columns
+    assert torch.equal(tf.unnormalized(X, cols=cols), tf.unnormalized(X)[:, 160:160 + 1696])
+    assert full.shape == (batch, 2000, 44)
