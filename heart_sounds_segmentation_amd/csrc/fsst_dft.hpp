@@ -38,13 +38,16 @@ struct DftParams {
     float r2scale;
 };
 
-__host__ __device__ constexpr int dft_xs_floats(int nk4) { return ((16 + 4 * nk4 + 3) / 4) * 4; }
-__host__ __device__ constexpr int dft_wave_lds_floats(int nk4, int K)
+// G = 16-frame groups per work item (a tile of 16 G frames): every A-operand load feeds G MFMAs on G independent
+// accumulators (the constants come from L2: one group per item is bound by those loads -- nwin 1024: 1.3 k windows/s).
+__host__ __device__ constexpr int dft_xs_floats(int nk4, int G = 1) { return ((16 * G + 4 * nk4 + 3) / 4) * 4; }
+__host__ __device__ constexpr int dft_wave_lds_floats(int nk4, int K, int G = 1)
 {
-    return dft_xs_floats(nk4) + 2 * 16 * plane_ldf(K) + 4 + kTieWords;
+    return dft_xs_floats(nk4, G) + 2 * 16 * G * plane_ldf(K) + 4 + kTieWords;
 }
 
-// One wave = one 16-frame group at a time (grid-stride over batch x groups); blockDim = 64 x (waves that fit the LDS).
+// One wave = one tile of G groups at a time (grid-stride over batch x tiles); blockDim = 64 x (waves that fit the LDS).
+template <int G>
 __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -53,13 +56,15 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
     const int g = lane >> 4, j = lane & 15;
     const int N = p.nwin, K = p.K, klo = p.klo, nf = p.nf, m = N / 2;
     const int LDP = plane_ldf(K);
-    const int XS = dft_xs_floats(p.nk4);
-    float* xs = smem + wv * dft_wave_lds_floats(p.nk4, K);
+    constexpr int F = 16 * G;                              // frames per tile
+    const int XS = dft_xs_floats(p.nk4, G);
+    float* xs = smem + wv * dft_wave_lds_floats(p.nk4, K, G);
     f2* plane = reinterpret_cast<f2*>(xs + XS);
-    int* flag = reinterpret_cast<int*>(plane + 16 * LDP);
+    int* flag = reinterpret_cast<int*>(plane + F * LDP);
     int* tq = flag + 4;
     if (lane == 0) tq[0] = 0;
-    const int ngroups = (p.ncols + 15) >> 4;
+    const int ngroups = (p.ncols + 15) >> 4;             // statistics partials stay per 16-frame group
+    const int ntiles = (p.ncols + F - 1) / F;
     const int cend = p.col0 + p.ncols;
     const bool even = (N & 1) == 0;
 
@@ -80,36 +85,44 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
     };
 
     for (long long item = static_cast<long long>(blockIdx.x) * nwv + wv; item < p.nitems; item += static_cast<long long>(gridDim.x) * nwv) {
-        const long long b = item / ngroups;
-        const int gidx = static_cast<int>(item - b * ngroups);
-        const int tg = p.col0 + gidx * 16, tr = gidx * 16;
+        const long long b = item / ntiles;
+        const int tidx = static_cast<int>(item - b * ntiles);
+        const int tg = p.col0 + tidx * F, tr = tidx * F;
         const float* xsig = p.x + b * p.xstride;
         // stage the zero-padded tile xs[i] = xpad[tg + i] = x[tg + i - m]; sum x^2 for the error bound of displaced cells
         float e2 = 0.0f;
         for (int i = lane; i < XS; i += 64) {
             const int gi = tg + i - m;
-            const float v = (i < 16 + N - 1 && gi >= 0 && gi < p.n) ? xsig[gi] : 0.0f;
+            const float v = (i < F + N - 1 && gi >= 0 && gi < p.n) ? xsig[gi] : 0.0f;
             xs[i] = v;
             e2 = fmaf(v, v, e2);
         }
         const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
-        for (int i = lane; i < 16 * LDP; i += 64) plane[i] = f2{0.0f, 0.0f};
+        for (int i = lane; i < F * LDP; i += 64) plane[i] = f2{0.0f, 0.0f};
         wave_sync();
 
         const float* xb = xs + j + g;                            // B[k = g][frame j] of k-step ks: xs[j + 4 ks + g]
         for (int blk = 0; blk < p.nblk4; ++blk) {
             const float* ab = p.atab + (static_cast<size_t>(blk) * p.nk4) * 64 + lane;
-            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-            for (int ks = 0; ks < p.nk4; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[ks * 64], xb[4 * ks], acc, 0, 0, 0);
-            const int kp = 4 * blk + g;                          // this lane's source, frame j
+            f4 acc[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) acc[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int ks = 0; ks < p.nk4; ++ks) {
+                const float a = ab[ks * 64];
+#pragma unroll
+                for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[4 * ks + 16 * q], acc[q], 0, 0, 0);
+            }
+            const int kp = 4 * blk + g;                          // this lane's source, frames j + 16 q
+#pragma unroll
+            for (int q = 0; q < G; ++q)
             if (kp < nf) {
-                const float vr = acc.x, vi = acc.y, dr = acc.z, di = acc.w;
+                const int jq = j + 16 * q;
+                const float vr = acc[q].x, vi = acc[q].y, dr = acc[q].z, di = acc[q].w;
                 const float den = fmaf(vr, vr, fmaf(vi, vi, 1.0e-37f));
                 const float num = fmaf(dr, vi, -(di * vr));      // shift = -Im(Vd'/V) = num / den (bins)
                 if (fabsf(num) < (0.5f - kTieMargin) * den) {
-                    add(j, kp - klo, vr, vi);                    // stays in its own row
+                    add(jq, kp - klo, vr, vi);                    // stays in its own row
                 } else {
                     float shift = num * __builtin_amdgcn_rcpf(den);
                     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f; // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
                     if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {
                         const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (slot < kTieQueue) {
-                            tq[4 + 3 * slot] = kp | (j << 16);
+                            tq[4 + 3 * slot] = kp | (jq << 16);
                             tq[5 + 3 * slot] = __float_as_int(vr);
                             tq[6 + 3 * slot] = __float_as_int(vi);
                             queued = true;
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
                         const float r = truncf(a + copysignf(0.5f, a));      // MATLAB round: half away from zero
                         int row = static_cast<int>(r) % N;
                         if (row < 0) row += N;
-                        land(j, kp, row, vr, vi);
+                        land(jq, kp, row, vr, vi);
                     }
                 }
             }
@@ -170,39 +183,45 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
             wave_sync();
         }
 
-        // ---- epilogue for these 16 frames
-        const int nvalid = min(16, cend - tg);
-        if (p.mode == kModeRaw) {
-            float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(p.ncols) + tr;
-            for (int e = lane; e < K * 16; e += 64) {
-                const int k = e >> 4, jj = e & 15;
-                if (jj < nvalid) {
-                    const f2 v = plane[jj * LDP + k];
-                    dst[static_cast<long long>(k) * p.ncols + jj] = make_float2(v.x, v.y);
+        // ---- epilogue for these F frames, one 16-frame group (= one statistics partial) at a time
+        for (int q = 0; q < G; ++q) {
+            const int gidx = tidx * G + q;
+            if (gidx >= ngroups) break;
+            const int tgq = tg + 16 * q, trq = tr + 16 * q;
+            const f2* pl = plane + 16 * q * LDP;
+            const int nvalid = min(16, cend - tgq);
+            if (p.mode == kModeRaw) {
+                float2* dst = reinterpret_cast<float2*>(p.out) + (b * K) * static_cast<long long>(p.ncols) + trq;
+                for (int e = lane; e < K * 16; e += 64) {
+                    const int k = e >> 4, jj = e & 15;
+                    if (jj < nvalid) {
+                        const f2 v = pl[jj * LDP + k];
+                        dst[static_cast<long long>(k) * p.ncols + jj] = make_float2(v.x, v.y);
+                    }
                 }
-            }
-        } else if (p.mode == kModeAbs) {
-            float* dst = p.out + (b * static_cast<long long>(p.ncols) + tr) * K;
-            for (int e = lane; e < nvalid * K; e += 64) {
-                const int jj = e / K, k = e - jj * K;
-                const f2 v = plane[jj * LDP + k];
-                dst[e] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
-            }
-        } else {
-            const int C = 2 * K;
-            float* dst = p.out + (b * static_cast<long long>(p.ncols) + tr) * C;
-            const f2 piv = plane[0];                             // statistics pivot: frame 0, row klo
-            float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
-            for (int e = lane; e < nvalid * C; e += 64) {
-                const int jj = e / C, c = e - jj * C;
-                float val;
-                if (c < K) { val = plane[jj * LDP + c].x; const float d = val - piv.x; s_re += d; q_re = fmaf(d, d, q_re); }
-                else       { val = plane[jj * LDP + c - K].y; const float d = val - piv.y; s_im += d; q_im = fmaf(d, d, q_im); }
-                dst[e] = val;
-            }
-            if (p.mode == kModeStack) {
-                const float w = piece_sums(s_re, q_re, s_im, q_im);
-                store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
+            } else if (p.mode == kModeAbs) {
+                float* dst = p.out + (b * static_cast<long long>(p.ncols) + trq) * K;
+                for (int e = lane; e < nvalid * K; e += 64) {
+                    const int jj = e / K, k = e - jj * K;
+                    const f2 v = pl[jj * LDP + k];
+                    dst[e] = sqrtf(fmaf(v.x, v.x, v.y * v.y));
+                }
+            } else {
+                const int C = 2 * K;
+                float* dst = p.out + (b * static_cast<long long>(p.ncols) + trq) * C;
+                const f2 piv = pl[0];                            // statistics pivot: the group's frame 0, row klo
+                float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
+                for (int e = lane; e < nvalid * C; e += 64) {
+                    const int jj = e / C, c = e - jj * C;
+                    float val;
+                    if (c < K) { val = pl[jj * LDP + c].x; const float d = val - piv.x; s_re += d; q_re = fmaf(d, d, q_re); }
+                    else       { val = pl[jj * LDP + c - K].y; const float d = val - piv.y; s_im += d; q_im = fmaf(d, d, q_im); }
+                    dst[e] = val;
+                }
+                if (p.mode == kModeStack) {
+                    const float w = piece_sums(s_re, q_re, s_im, q_im);
+                    store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
+                }
             }
         }
         wave_sync();

@@ -736,16 +736,37 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
             dp.n = n; dp.nwin = p->nwin; dp.nf = p->nf; dp.klo = p->klo; dp.K = p->K; dp.mode = p->mode; dp.col0 = col0; dp.ncols = ncols;
             dp.nk4 = (p->nwin + 3) / 4; dp.nblk4 = (p->nf + 3) / 4;
             dp.nitems = static_cast<long long>(cb) * nblk; dp.xstride = x_stride; dp.r2scale = p->r2scale;
-            const size_t per_wave = static_cast<size_t>(hssfsst::dft_wave_lds_floats(dp.nk4, p->K)) * sizeof(float);
+            // groups per work item: 4 when four planes fit the LDS of a wave (each A-operand load then feeds four MFMAs),
+            // else 2, else 1; then as many waves per block as fit (at most 8)
+            // largest tile that still leaves >= 16 waves resident per CU (the MFMA chains are dependent: latency is hidden
+            // by waves, not by the tile), else whatever keeps the most waves (measured: nwin 100 is fastest with small tiles)
+            int G = 1, best_waves = -1;
+            for (int cand = 4; cand >= 1; cand >>= 1) {
+                const size_t pw = static_cast<size_t>(hssfsst::dft_wave_lds_floats(dp.nk4, p->K, cand)) * sizeof(float);
+                int w = static_cast<int>(static_cast<size_t>(kMaxLdsBytes) / pw);
+                if (w > 8) w = 8;
+                if (w < 1) continue;
+                int per_cu = static_cast<int>(static_cast<size_t>(kMaxLdsBytes) / (pw * w)) * w;
+                if (per_cu > 32) per_cu = 32;
+                if (per_cu >= 16) { G = cand; best_waves = per_cu; break; }
+                if (per_cu > best_waves) { G = cand; best_waves = per_cu; }
+            }
+            if (ncols <= 16) G = 1;
+            const size_t per_wave = static_cast<size_t>(hssfsst::dft_wave_lds_floats(dp.nk4, p->K, G)) * sizeof(float);
             int waves = static_cast<int>(static_cast<size_t>(kMaxLdsBytes) / per_wave);
             if (waves > 8) waves = 8;
             if (waves < 1) return fail(HSSFSST_EUNSUPPORTED, "exec: LDS request %zu B per wave exceeds 160 KiB", per_wave);
-            static std::atomic<unsigned long long> lds_ok{0};
-            if ((rc = allow_full_lds(hssfsst::fsst_dft_kernel, p->device, lds_ok)) != 0) return rc;
+            const int ntiles = (ncols + 16 * G - 1) / (16 * G);
+            dp.nitems = static_cast<long long>(cb) * ntiles;
             long long blocks = (dp.nitems + waves - 1) / waves;
             if (blocks > 256 * 64) blocks = 256 * 64;                       // grid-stride beyond that
-            hipLaunchKernelGGL(hssfsst::fsst_dft_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64 * waves), per_wave * waves, st, dp);
-            rc = (hipGetLastError() == hipSuccess) ? 0 : fail(HSSFSST_EHIP, "exec: fsst_dft_kernel launch failed");
+            auto launch = [&](auto kern) -> int {
+                static std::atomic<unsigned long long> lds_ok{0};
+                if (int r2 = allow_full_lds(kern, p->device, lds_ok)) return r2;
+                hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * waves), per_wave * waves, st, dp);
+                return (hipGetLastError() == hipSuccess) ? 0 : fail(HSSFSST_EHIP, "exec: fsst_dft_kernel launch failed");
+            };
+            rc = (G == 4) ? launch(hssfsst::fsst_dft_kernel<4>) : (G == 2) ? launch(hssfsst::fsst_dft_kernel<2>) : launch(hssfsst::fsst_dft_kernel<1>);
         } else if (use128) {
             rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st, !no_fused && !piped, &did_fuse);
         } else switch (p->R) {
