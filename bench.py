@@ -32,12 +32,12 @@ VALU_FLOP_PER_LANE = 2.0                         # estimate: the VALU mix is ~ha
 
 
 def csrc_digest():
-    """SHA-256 of the kernel sources (the device code: csrc/*.hpp): PMC figures committed under profiles/ are only
-    quoted for the kernels they were measured on."""
+    """SHA-256 of the device code of the benchmarked kernels (csrc/fsst_mfma128.hpp + csrc/fsst_kernels.hpp): PMC
+    figures committed under profiles/ are only quoted for the kernels they were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "heart_sounds_segmentation_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith(".hpp"):
+        if f in ("fsst_mfma128.hpp", "fsst_kernels.hpp"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
