@@ -642,19 +642,25 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
                     o[q][i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
                 }
             }
+            // this lane's {mean, 1/std} per float4 and pair, once per ticket (the column classes do not depend on the group)
+            f2 mu[3][2], rs[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
+                const float m0 = im0 ? st.z : st.x, r0 = im0 ? st.w : st.y;
+                const float m1 = im1 ? st.z : st.x, r1 = im1 ? st.w : st.y;
+                mu[i][0] = f2{m0, m0}; rs[i][0] = f2{r0, r0};
+                mu[i][1] = f2{m1, m1}; rs[i][1] = f2{r1, r1};
+            }
 #pragma unroll
             for (int q = 0; q < GPCF; ++q) {
                 const int lim = glim(q);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (lane_o + 64 * i < lim) {
-                        const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
-                        const float m0 = im0 ? st.z : st.x, r0 = im0 ? st.w : st.y;
-                        const float m1 = im1 ? st.z : st.x, r1 = im1 ? st.w : st.y;
-                        f4 r;
-                        r.x = (o[q][i].x - m0) * r0; r.y = (o[q][i].y - m0) * r0;
-                        r.z = (o[q][i].z - m1) * r1; r.w = (o[q][i].w - m1) * r1;
-                        __builtin_nontemporal_store(r, reinterpret_cast<f4*>(d4 + q * per + 64 * i));
+                        const f2 lo = (f2{o[q][i].x, o[q][i].y} - mu[i][0]) * rs[i][0];     // (v - mean) * (1 / std): two roundings,
+                        const f2 hi = (f2{o[q][i].z, o[q][i].w} - mu[i][1]) * rs[i][1];     // exactly as fsst_normalize_kernel
+                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + q * per + 64 * i));
                     }
                 }
             }
