@@ -597,38 +597,68 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
 // (Chan's pairwise merge == repeated application of update_mean/update_variance, in exact
 // arithmetic).  grid = batch, block = 256.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsst_moments_merge_kernel(const float* feats, double* state,
-                                                                 int n, int K)
+// Block-wide sums {sum re, sum re^2, sum im, sum im^2} (float64) of one signal's [n][2K] features: every thread of a
+// 1024-thread block gets the totals.  Fixed order (thread-strided, wave butterflies, then the 16 waves in index order):
+// the same numbers whichever kernel calls it.  16-byte loads when the block is float4-addressable; the column of an
+// element is tracked without a division per element.
+constexpr int kMomThreads = 1024;
+__device__ inline void chunk_moments(const float* base, int total, int C, int K, int tid, double (*red)[4], double out[4])
 {
-    __shared__ double red[4][4];
-    const long long b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int C = 2 * K;
-    const long long total = static_cast<long long>(n) * C;
-    const float* base = feats + b * total;
     double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
-    for (long long i = tid; i < total; i += 256) {
-        const int c = static_cast<int>(i % C);
-        const double v = static_cast<double>(base[i]);
+    auto acc = [&](float f, int c) {
+        const double v = static_cast<double>(f);
         if (c < K) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
+    };
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        const int tot4 = total >> 2;
+        int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
+        const int dc = static_cast<int>((static_cast<unsigned>(kMomThreads) * 4u) % static_cast<unsigned>(C));
+        for (int i = tid; i < tot4; i += kMomThreads) {
+            const float4 v = b4[i];
+            int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+            if (c1 >= C) c1 -= C;
+            if (c2 >= C) c2 -= C;
+            if (c3 >= C) c3 -= C;
+            acc(v.x, c); acc(v.y, c1); acc(v.z, c2); acc(v.w, c3);
+            c += dc;
+            if (c >= C) c -= C;
+        }
+    } else {
+        for (int i = tid; i < total; i += kMomThreads) acc(base[i], i % C);
     }
     s0 = wave_sum(s0); q0 = wave_sum(q0); s1 = wave_sum(s1); q1 = wave_sum(q1);
     if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = q0; red[tid >> 6][2] = s1; red[tid >> 6][3] = q1; }
     __syncthreads();
-    if (tid < 2) {
-        double s = 0, q = 0;
-        for (int w2 = 0; w2 < 4; ++w2) { s += red[w2][tid * 2]; q += red[w2][tid * 2 + 1]; }
-        const double nb = static_cast<double>(K) * static_cast<double>(n);
-        const double mean_b = s / nb;
-        const double m2_b = q - s * mean_b;
-        double* st = state + b * 6 + tid * 3;
-        const double na = st[0], mean_a = st[1], m2_a = st[2];
-        const double nn = na + nb;
-        const double delta = mean_b - mean_a;
-        st[0] = nn;
-        st[1] = mean_a + delta * (nb / nn);
-        st[2] = m2_a + m2_b + delta * delta * (na * nb / nn);
-    }
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (int w2 = 0; w2 < kMomThreads / 64; ++w2)
+        for (int e = 0; e < 4; ++e) out[e] += red[w2][e];
+}
+
+// Chan merge of one block {sum, sum of squares over nb elements} into the running {count, mean, M2} at st[0..2];
+// returns the float32 {mean, 1 / unbiased std} of the merged state
+__device__ inline float2 merge_state(double* st, double s, double q, double nb)
+{
+    const double mean_b = s / nb;
+    const double m2_b = q - s * mean_b;
+    const double na = st[0], mean_a = st[1], m2_a = st[2];
+    const double nn = na + nb;
+    const double delta = mean_b - mean_a;
+    const double mean_n = mean_a + delta * (nb / nn);
+    const double m2_n = m2_a + m2_b + delta * delta * (na * nb / nn);
+    st[0] = nn; st[1] = mean_n; st[2] = m2_n;
+    return make_float2(static_cast<float>(mean_n), 1.0f / static_cast<float>(sqrt(m2_n / (nn - 1.0))));
+}
+
+__global__ __launch_bounds__(kMomThreads) void fsst_moments_merge_kernel(const float* feats, double* state, int n, int K)
+{
+    __shared__ double red[kMomThreads / 64][4];
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int total = n * 2 * K;                         // < 2^31, checked on the host
+    double m[4];
+    chunk_moments(feats + b * static_cast<long long>(total), total, 2 * K, K, tid, red, m);
+    if (tid < 2) merge_state(state + b * 6 + tid * 3, m[2 * tid], m[2 * tid + 1], static_cast<double>(K) * static_cast<double>(n));
 }
 
 // Running-moments normalisation (streaming): stats[b] from the {count, mean, M2} state of
@@ -641,6 +671,54 @@ __global__ __launch_bounds__(64) void fsst_stats_from_state_kernel(const double*
     const double vr = st[2] / (st[0] - 1.0), vi = st[5] / (st[3] - 1.0);
     stats[b] = make_float4(static_cast<float>(st[1]), 1.0f / static_cast<float>(sqrt(vr)),
                            static_cast<float>(st[4]), 1.0f / static_cast<float>(sqrt(vi)));
+}
+
+// One streaming step's tail in ONE launch (hssfsst_stream_step): block b merges the new un-normalised chunk of channel b
+// into its running {count, mean, M2} and then normalises that chunk with the updated moments.  Same arithmetic, same
+// order as fsst_moments_merge_kernel -> fsst_stats_from_state_kernel -> fsst_normalize_kernel: bit-identical results,
+// two launches (and the statistics round trip through HBM) fewer per step.  grid = channels, block = 1024.
+__global__ __launch_bounds__(kMomThreads) void fsst_stream_finish_kernel(float* feats, double* state, int n, int K)
+{
+    __shared__ double red[kMomThreads / 64][4];
+    __shared__ float4 st_sh;
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int C = 2 * K;
+    const int total = n * C;                             // < 2^31, checked on the host
+    float* base = feats + b * static_cast<long long>(total);
+    double m[4];
+    chunk_moments(base, total, C, K, tid, red, m);
+    if (tid < 2) {
+        const float2 r = merge_state(state + b * 6 + tid * 3, m[2 * tid], m[2 * tid + 1], static_cast<double>(K) * static_cast<double>(n));
+        if (tid == 0) { st_sh.x = r.x; st_sh.y = r.y; } else { st_sh.z = r.x; st_sh.w = r.y; }
+    }
+    __syncthreads();
+    const float m_re = st_sh.x, i_re = st_sh.y, m_im = st_sh.z, i_im = st_sh.w;
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        float4* b4 = reinterpret_cast<float4*>(base);
+        const int tot4 = total >> 2;
+        int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
+        const int dc = static_cast<int>((static_cast<unsigned>(kMomThreads) * 4u) % static_cast<unsigned>(C));
+        for (int i = tid; i < tot4; i += kMomThreads) {
+            float4 v = b4[i];
+            int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+            if (c1 >= C) c1 -= C;
+            if (c2 >= C) c2 -= C;
+            if (c3 >= C) c3 -= C;
+            v.x = (c < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+            v.y = (c1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+            v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+            v.w = (c3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
+            b4[i] = v;
+            c += dc;
+            if (c >= C) c -= C;
+        }
+    } else {
+        for (int i = tid; i < total; i += kMomThreads) {
+            const float v = base[i];
+            base[i] = ((i % C) < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
+        }
+    }
 }
 
 }  // namespace hssfsst

@@ -82,7 +82,7 @@ struct Core128Params {
 // quarter or so, then 2-group chunks at the very end (each chunk costs a counter draw, a tile staging and a
 // statistics reduction, so the small ones are kept to the tail).  Measured (tools/tail_sweep.sh): (16, 6) 0.1691 ms,
 // (24, 2) 0.1683, (32, 6) 0.1701, (8, 4) 0.1738, 8-group chunks only 0.1749.
-inline Core128Regions core128_regions(int ngroups)
+inline Core128Regions core128_regions(int ngroups, long long nsig = -1)
 {
     Core128Regions r{};
 #ifdef HSS_TAIL_ENV                                      // development only (tools/tail_sweep.sh)
@@ -95,11 +95,14 @@ inline Core128Regions core128_regions(int ngroups)
 #endif
     if (ngroups < 32) {
         // short signals / streaming steps (a rolling transform adds 8 groups per step): parallelism matters more than
-        // the per-chunk overhead -- 2-group chunks up to 8 groups, 4-group chunks up to 31
-        const int gpc = ngroups <= 8 ? 2 : 4;
+        // the per-chunk overhead -- 2-group chunks up to 8 groups, 4-group chunks up to 31; and single groups when
+        // the whole launch is smaller than the chip (one streaming step of 64 channels = 512 groups for 1024 SIMDs:
+        // the step's latency is then one group, not two)
+        const bool tiny = nsig >= 0 && ngroups <= 8 && nsig * ngroups <= 1024;
+        const int gpc = tiny ? 1 : ngroups <= 8 ? 2 : 4;
         r.g0[0] = 0; r.gpc[0] = 8; r.npc[0] = 0;
         r.g0[1] = 0; r.gpc[1] = 4; r.npc[1] = gpc == 4 ? (ngroups + 3) / 4 : 0;
-        r.g0[2] = 0; r.gpc[2] = 2; r.npc[2] = gpc == 2 ? (ngroups + 1) / 2 : 0;
+        r.g0[2] = 0; r.gpc[2] = gpc == 1 ? 1 : 2; r.npc[2] = gpc == 1 ? ngroups : gpc == 2 ? (ngroups + 1) / 2 : 0;
         return r;
     }
     int big = ngroups - tail2 - tail4;

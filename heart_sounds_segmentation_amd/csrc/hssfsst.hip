@@ -289,7 +289,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     cp.wtab = pl->d_wtab; cp.twtab = pl->d_wtab + 2 * pl->nwin; cp.r2scale = pl->r2scale;
     cp.n = n; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = static_cast<int>(batch);
     cp.col0 = col0; cp.ncols = ncols;
-    cp.reg = hssfsst::core128_regions((ncols + 15) / 16);
+    cp.reg = hssfsst::core128_regions((ncols + 15) / 16, batch);
     const int64_t nchunks = batch * hssfsst::core128_chunks_per_signal(cp.reg);
     const bool fast = (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM) &&
                       (pl->K & 1) == 0 && pl->K <= 24;
@@ -841,9 +841,9 @@ int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, in
 {
     if (!p || !feats || !state || batch < 0 || n < 1) return fail(HSSFSST_EINVAL, "moments_merge: bad argument");
     if (batch == 0 || p->K == 0) return 0;
-    if (batch > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "moments_merge: batch too large");
+    if (batch > 0x7fffffffLL || static_cast<long long>(n) * 2 * p->K >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "moments_merge: too large");
     DEVICE_SCOPE(p->device);
-    hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
+    hipLaunchKernelGGL(hssfsst::fsst_moments_merge_kernel, dim3(static_cast<unsigned>(batch)), dim3(hssfsst::kMomThreads), 0,
                        static_cast<hipStream_t>(stream), feats, state, n, p->K);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -906,6 +906,40 @@ int hssfsst_normalize_running(hssfsst_plan* p, float* feats, int64_t batch, int 
     hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, st,
                        feats, stats, static_cast<const float*>(nullptr), 0, 0, n, p->K, static_cast<int>(batch), 1);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t pos, const float* x_new, int64_t x_stride,
+                        int x_on_device, int channels, int chunk, float* out, double* state, float* out_host,
+                        void* stream)
+{
+    if (!p || !tape || !x_new || !out || channels < 1 || chunk < 1 || x_stride < chunk)
+        return fail(HSSFSST_EINVAL, "stream_step: bad argument");
+    if (p->mode != HSSFSST_MODE_STACK_UNNORM) return fail(HSSFSST_EINVAL, "stream_step: the plan must be STACK_UNNORM");
+    const int64_t hist = p->nwin - 1;
+    if (pos < hist || pos + chunk > tape_len)
+        return fail(HSSFSST_EINVAL, "stream_step: pos %lld outside [nwin - 1, tape_len - chunk] (tape_len %lld, chunk %d)",
+                    static_cast<long long>(pos), static_cast<long long>(tape_len), chunk);
+    if (hist + chunk > 0x7fffffffLL || static_cast<long long>(chunk) * 2 * p->K >= 0x7fffffffLL)
+        return fail(HSSFSST_EINVAL, "stream_step: chunk too large");
+    if (p->K == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DEVICE_SCOPE(p->device);
+    HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
+                             static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels),
+                             x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    // frame j of the chunk = samples [pos - hist + j, pos - hist + j + nwin): column nwin/2 + j of the zero-padded
+    // transform of the last hist + chunk samples
+    int rc = hssfsst_exec_frames(p, tape + (pos - hist), channels, static_cast<int>(hist + chunk), tape_len, p->nwin / 2, chunk, 1, out, 1, stream);
+    if (rc != 0) return rc;
+    if (state) {
+        hipLaunchKernelGGL(hssfsst::fsst_stream_finish_kernel, dim3(static_cast<unsigned>(channels)), dim3(hssfsst::kMomThreads), 0, st, out, state, chunk, p->K);
+        HIP_TRY(hipGetLastError());
+    }
+    if (out_host) {
+        HIP_TRY(hipMemcpyAsync(out_host, out, static_cast<size_t>(channels) * chunk * 2 * p->K * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -17,6 +17,10 @@ No allocation per step: the history lives in ONE preallocated device buffer per 
 transforms the last ``nwin - 1 + chunk`` samples in place (``x_stride`` = tape length); only when the
 tape is full (every ``slots`` steps) the last ``nwin - 1`` samples are copied back to its start.  The
 feature output and the pinned host staging buffers of ``step_host`` are preallocated too.
+
+A step is ONE native call, ``hssfsst_stream_step`` (include/hssfsst.h): strided copy of the chunk into the tape
+(straight from pinned host memory in ``step_host``), the transform, one launch that merges the running moments and
+normalises with them, and -- ``step_host`` -- the copy back plus the one synchronisation.
 """
 from __future__ import annotations
 
@@ -52,11 +56,32 @@ class StreamingFSST:
         self.out = torch.empty((self.channels, self.chunk, 2 * self.K), dtype=torch.float32, device=self.device)
         self._pin_in = None
         self._pin_out = None
+        self._keep = None
 
     # kept for callers / tests that looked at the history of the first implementation
     @property
     def ring(self) -> torch.Tensor:
         return self.tape[:, self.pos - self.hist:self.pos]
+
+    def _make_room(self) -> None:
+        if self.pos + self.chunk > self.tape_len:          # tape full: history back to the start (every `slots` steps)
+            self._wrap.copy_(self.tape[:, self.pos - self.hist:self.pos])     # (two hops: the ranges may overlap)
+            self.tape[:, :self.hist].copy_(self._wrap)
+            self.pos = self.hist
+
+    def _native_step(self, x_ptr: int, x_stride: int, x_on_device: bool, host_out_ptr: Optional[int]) -> None:
+        """One ``hssfsst_stream_step``: copy the chunk into the tape, transform, merge + normalise, and (host_out_ptr)
+        copy the features to pinned host memory and wait -- 3 launches (+ the copies), one C call."""
+        self._make_room()
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(L.hssfsst_stream_step(self._plan.handle, ctypes.c_void_p(self.tape.data_ptr()), self.tape_len, self.pos,
+                                         ctypes.c_void_p(x_ptr), x_stride, 1 if x_on_device else 0, self.channels, self.chunk,
+                                         ctypes.c_void_p(self.out.data_ptr()),
+                                         ctypes.c_void_p(self.state.data_ptr()) if self.normalize else None,
+                                         ctypes.c_void_p(host_out_ptr) if host_out_ptr else None, stream),
+                   "hssfsst_stream_step")
+        self.pos += self.chunk
 
     def step(self, x_new: torch.Tensor) -> torch.Tensor:
         """``x_new``: ``(channels, chunk)`` newest samples (device tensor preferred).  Returns
@@ -65,10 +90,21 @@ class StreamingFSST:
         overwritten by the next step."""
         if tuple(x_new.shape) != (self.channels, self.chunk):
             raise ValueError(f"StreamingFSST.step: expected {(self.channels, self.chunk)}, got {tuple(x_new.shape)}")
-        if self.pos + self.chunk > self.tape_len:          # tape full: history back to the start (every `slots` steps)
-            self._wrap.copy_(self.tape[:, self.pos - self.hist:self.pos])     # (two hops: the ranges may overlap)
-            self.tape[:, :self.hist].copy_(self._wrap)
-            self.pos = self.hist
+        if x_new.dtype != torch.float32 or x_new.stride(1) != 1 or x_new.stride(0) < self.chunk:
+            x_new = x_new.to(torch.float32).contiguous()   # (a column slice of a wider row-major tensor is taken as it is)
+        if x_new.is_cuda and x_new.device != self.device:
+            x_new = x_new.to(self.device)
+        self._native_step(x_new.data_ptr(), x_new.stride(0), x_new.is_cuda, None)
+        self._keep = x_new                                 # the copy is asynchronous: keep the source alive until the next step
+        return self.out
+
+    def step_unfused(self, x_new: torch.Tensor) -> torch.Tensor:
+        """The same step as separate calls (copy, ``hssfsst_exec_frames``, ``hssfsst_moments_merge``,
+        ``hssfsst_normalize_running``): what ``step`` did before ``hssfsst_stream_step`` existed; kept for the
+        bit-equality test of the two routes."""
+        if tuple(x_new.shape) != (self.channels, self.chunk):
+            raise ValueError(f"StreamingFSST.step: expected {(self.channels, self.chunk)}, got {tuple(x_new.shape)}")
+        self._make_room()
         self.tape[:, self.pos:self.pos + self.chunk].copy_(x_new, non_blocking=True)
         L = _lib.lib()
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -89,13 +125,14 @@ class StreamingFSST:
 
     def step_host(self, x_new: np.ndarray) -> np.ndarray:
         """Host in, host out (the latency BASELINE config 5 asks for: last sample of a chunk on the host ->
-        its features on the host): pinned staging buffers, one H2D copy, the kernels, one D2H copy, one
-        synchronisation.  Returns a view of the pinned output buffer (overwritten by the next call)."""
+        its features on the host): pinned staging buffers and ONE native call -- H2D copy straight into the tape, the
+        kernels, D2H copy, one synchronisation.  Returns a view of the pinned output buffer (overwritten by the next
+        call)."""
         if self._pin_in is None:
             self._pin_in = torch.empty((self.channels, self.chunk), dtype=torch.float32).pin_memory()
             self._pin_out = torch.empty((self.channels, self.chunk, 2 * self.K), dtype=torch.float32).pin_memory()
-        self._pin_in.numpy()[...] = x_new
-        feats = self.step(self._pin_in)
-        self._pin_out.copy_(feats, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        return self._pin_out.numpy()
+            self._pin_out_np = self._pin_out.numpy()
+            self._pin_in_np = self._pin_in.numpy()
+        self._pin_in_np[...] = x_new
+        self._native_step(self._pin_in.data_ptr(), self.chunk, False, self._pin_out.data_ptr())
+        return self._pin_out_np

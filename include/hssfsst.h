@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 200
+#define HSSFSST_VERSION 201
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -130,6 +130,24 @@ int hssfsst_moments_merge(hssfsst_plan* plan, const float* feats, int64_t batch,
  * `state` (as maintained by hssfsst_moments_merge): (v - mean) / sqrt(M2 / (count - 1)) per block. */
 int hssfsst_normalize_running(hssfsst_plan* plan, float* feats, int64_t batch, int n,
                               const double* state, void* stream);
+
+/* One step of the rolling transform (BASELINE config 5: C channels, `chunk` new samples per channel per step; no
+ * counterpart in the reference, built from the same path -- see heart_sounds_segmentation_amd/streaming.py).
+ * `tape`: float32 [channels][tape_len] on the device, the caller's sample history; the step
+ *   1. copies x_new ([channels] rows of `chunk` samples, x_stride >= chunk samples apart; device memory, or host
+ *      memory when x_on_device = 0 -- pinned for an asynchronous copy) to tape[:, pos .. pos + chunk),
+ *   2. transforms the `chunk` frames that end at the new samples (frames tape[:, pos - (nwin-1) + j ..], hop 1: no
+ *      frame touches padding) into `out` = float32 [channels][chunk][2K] on the device (plan mode STACK_UNNORM),
+ *   3. state != NULL: merges the chunk into the running moments `state` (float64 [channels][6], as
+ *      hssfsst_moments_merge) and normalises `out` with the UPDATED moments (as hssfsst_normalize_running) in one
+ *      launch -- bit-identical to calling the two,
+ *   4. out_host != NULL: copies `out` to out_host (pinned host memory) and waits for the stream: when the call
+ *      returns the features of this step are on the host (the latency BASELINE config 5 asks for).
+ * Requires nwin - 1 <= pos and pos + chunk <= tape_len; the caller moves the history back to the start of the
+ * tape when it is full. */
+int hssfsst_stream_step(hssfsst_plan* plan, float* tape, int64_t tape_len, int64_t pos, const float* x_new,
+                        int64_t x_stride, int x_on_device, int channels, int chunk, float* out, double* state,
+                        float* out_host, void* stream);
 
 /* Host helper, no device needed: parser for the corpus files read by DavidSpringerHSS._load_file
  * (hss/datasets/heart_sounds.py:193-197: pd.read_csv(skiprows=1, names=["Signals", "Labels"])):

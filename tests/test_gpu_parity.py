@@ -39,8 +39,10 @@ def _run_and_check(oracle_mod, X, fs, window, band, abs_=False, stack=False, wha
 
 
 def test_library_loaded_and_device():
+    import re
     L = _lib.lib()
-    assert L.hssfsst_version() == 200
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hssfsst.h")).read()
+    assert L.hssfsst_version() == int(re.search(r"#define HSSFSST_VERSION (\d+)", header).group(1))
     assert L.hssfsst_device_count() >= 1
 
 
@@ -440,6 +442,32 @@ def test_streaming_matches_offline(oracle_mod):
         sd = allre.flatten(1).std(dim=1, unbiased=True)[:, None, None]
         want = ((outs[i][..., :22].double() - m) / sd).float()
         assert (y[..., :22] - want).abs().max() < 2e-4 * want.abs().max()
+
+
+def test_stream_step_equals_separate_calls():
+    """hssfsst_stream_step (copy into the tape + transform + ONE merge-and-normalise launch, optionally D2H + wait)
+    gives bit for bit what hssfsst_exec_frames + hssfsst_moments_merge + hssfsst_normalize_running give, on the
+    device route and on the pinned-host route, across tape wraps, for two window lengths; so do the running moments."""
+    from scipy.signal import get_window
+    from heart_sounds_segmentation_amd.streaming import StreamingFSST
+    for fs, N, chunk, ch, steps in ((4000, 512, 128, 64, 7), (1000, 128, 48, 5, 9)):
+        w = get_window(("kaiser", 0.5), N, fftbins=False)
+        x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=11) + 0.25          # a DC offset: the moments matter
+        a = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True, slots=3)
+        b = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True, slots=3)
+        c = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True, slots=2)
+        xd = torch.from_numpy(x).cuda()
+        for i in range(steps):
+            xi = x[:, i * chunk:(i + 1) * chunk]
+            ya = a.step(xd[:, i * chunk:(i + 1) * chunk])                         # a strided view: copied row by row
+            yb = b.step_unfused(torch.from_numpy(np.ascontiguousarray(xi)).cuda())
+            yc = c.step_host(xi)
+            assert torch.equal(ya, yb), (N, i)
+            assert np.array_equal(yc, yb.cpu().numpy()), (N, i)
+            assert torch.equal(a.state, b.state) and torch.equal(c.state, b.state), (N, i)
+        assert torch.isfinite(ya).all()
+    with pytest.raises(ValueError):
+        a.step(torch.zeros(3, 3))
 
 
 def test_corpus_builder_and_end_to_end(oracle_mod):
