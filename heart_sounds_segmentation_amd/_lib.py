@@ -96,6 +96,8 @@ def lib():
         L.hssfsst_exec_frames.restype = c_int
         L.hssfsst_normalize_running.argtypes = [vp, vp, c_i64, c_int, vp, vp]
         L.hssfsst_normalize_running.restype = c_int
+        L.hssfsst_exec_list.argtypes = [vp, vp, c_i64, vp, c_int, c_i64, c_int, c_int, vp, c_int, vp]
+        L.hssfsst_exec_list.restype = c_int
         L.hssfsst_stream_step.argtypes = [vp, vp, c_i64, c_i64, vp, c_i64, c_int, c_int, c_int, vp, vp, vp, vp]
         L.hssfsst_stream_step.restype = c_int
         L.hssfsst_plan_last_exec_fused.argtypes = [vp]

@@ -18,6 +18,7 @@
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
 #include "fsst_dft.hpp"
+#include "fsst_gather.hpp"
 #include "fourier_resample.hpp"
 #include <cstdlib>
 
@@ -161,6 +162,8 @@ struct hssfsst_plan {
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
+    long long* d_starts = nullptr; size_t starts_cap = 0;    // frame-list staging (hssfsst_exec_list with host starts)
+    float* d_frames = nullptr;    size_t frames_cap = 0;     // frames gathered from a list, dense [batch][n]
     int timing = 0;
     std::vector<hipEvent_t> ev;   // per timed exec: (before, after) per core launch + one closing event
     size_t ev_used = 0;           // events used since timing was enabled
@@ -548,6 +551,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
+    if (p->d_starts) (void)hipFree(p->d_starts);
+    if (p->d_frames) (void)hipFree(p->d_frames);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : p->sync_ev) if (ev) (void)hipEventDestroy(ev);
     if (p->aux) (void)hipStreamDestroy(p->aux);
@@ -638,8 +643,13 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
     return hssfsst_exec_frames(p, x, batch, n, static_cast<int64_t>(n), col0, ncols, x_on_device, out, out_on_device, stream);
 }
 
-int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
-                        int x_on_device, float* out, int out_on_device, void* stream)
+// The one exec: `batch` signals of n samples, signal b at x + b * x_stride, or -- d_starts != nullptr (device array) --
+// at x + d_starts[b] inside a buffer of x_len samples.  A frame list is first gathered into a dense [batch][n] staging
+// buffer (fsst_gather_frames_kernel: 8 kB read + 8 kB written per frame, against 360 kB of output) and then takes the
+// same kernels as a dense batch: the transform kernels sit at the 128-VGPR limit of their occupancy and a second
+// addressing mode in them cost spilled registers.
+static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int64_t x_stride, const long long* d_starts,
+                     size_t x_len, int col0, int ncols, int x_on_device, float* out, int out_on_device, void* stream)
 {
     if (!p || !x || !out || batch < 0 || n < 1 || col0 < 0 || ncols < 1 || col0 > n - ncols || x_stride < 1)
         return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d stride=%lld col0=%d ncols=%d)",
@@ -656,7 +666,7 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
     if (nblocks > 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: batch*tiles = %lld exceeds the grid limit; split the batch", nblocks);
     if (static_cast<long long>(n) * 2 * p->nf >= 0x7fffffffLL) return fail(HSSFSST_EINVAL, "exec: signal too long (n = %d)", n);
     // input extent: `batch` signals of n samples whose starts are x_stride apart (they may overlap)
-    const size_t nx = static_cast<size_t>(batch > 0 ? batch - 1 : 0) * static_cast<size_t>(x_stride) + n;
+    const size_t nx = d_starts ? x_len : static_cast<size_t>(batch > 0 ? batch - 1 : 0) * static_cast<size_t>(x_stride) + n;
     const size_t no = static_cast<size_t>(batch) * ncols * ofps;
 
     const float* dx = x;
@@ -666,6 +676,18 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         if ((rc = grow(reinterpret_cast<void**>(&p->d_xstage), &p->xstage_cap, nx, sizeof(float))) != 0) return rc;
         HIP_TRY(hipMemcpyAsync(p->d_xstage, x, nx * sizeof(float), hipMemcpyHostToDevice, st));
         dx = p->d_xstage;
+    }
+    if (d_starts) {
+        const size_t nd = static_cast<size_t>(batch) * n;
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_frames), &p->frames_cap, nd, sizeof(float))) != 0) return rc;
+        const long long quads = (static_cast<long long>(n) + 3) / 4;
+        long long blocks = (static_cast<long long>(batch) * quads + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(hssfsst::fsst_gather_frames_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
+                           dx, d_starts, p->d_frames, static_cast<long long>(batch), n);
+        HIP_TRY(hipGetLastError());
+        dx = p->d_frames;
+        x_stride = n;
     }
     if (!out_on_device) {
         if ((rc = grow(reinterpret_cast<void**>(&p->d_ostage), &p->ostage_cap, no, sizeof(float))) != 0) return rc;
@@ -835,6 +857,36 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
         HIP_TRY(hipStreamSynchronize(st));   // the host source may be reused by the caller
     }
     return 0;
+}
+
+int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
+                        int x_on_device, float* out, int out_on_device, void* stream)
+{
+    return exec_impl(p, x, batch, n, x_stride, nullptr, 0, col0, ncols, x_on_device, out, out_on_device, stream);
+}
+
+int hssfsst_exec_list(hssfsst_plan* p, const float* x, int64_t x_len, const int64_t* starts, int starts_on_device,
+                      int64_t batch, int n, int x_on_device, float* out, int out_on_device, void* stream)
+{
+    if (!p || !x || !starts || !out || batch < 0 || n < 1 || x_len < n)
+        return fail(HSSFSST_EINVAL, "exec_list: bad argument (batch=%lld n=%d x_len=%lld)", static_cast<long long>(batch), n,
+                    static_cast<long long>(x_len));
+    if (batch == 0 || p->K == 0) return 0;
+    static_assert(sizeof(long long) == sizeof(int64_t), "frame starts are 64-bit");
+    const long long* d_starts = reinterpret_cast<const long long*>(starts);
+    if (!starts_on_device) {
+        for (int64_t b = 0; b < batch; ++b)
+            if (starts[b] < 0 || starts[b] > x_len - n)
+                return fail(HSSFSST_EINVAL, "exec_list: frame %lld starts at %lld, outside [0, %lld]", static_cast<long long>(b),
+                            static_cast<long long>(starts[b]), static_cast<long long>(x_len - n));
+        DEVICE_SCOPE(p->device);
+        int rc;
+        if ((rc = grow(reinterpret_cast<void**>(&p->d_starts), &p->starts_cap, static_cast<size_t>(batch), sizeof(long long))) != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_starts, starts, static_cast<size_t>(batch) * sizeof(long long), hipMemcpyHostToDevice,
+                               static_cast<hipStream_t>(stream)));
+        d_starts = p->d_starts;
+    }
+    return exec_impl(p, x, batch, n, 1, d_starts, static_cast<size_t>(x_len), 0, n, x_on_device, out, out_on_device, stream);
 }
 
 int hssfsst_moments_merge(hssfsst_plan* p, const float* feats, int64_t batch, int n, double* state, void* stream)

@@ -215,6 +215,51 @@ class FSST:
             raise ValueError(f"FSST.batch: expected (B, n), got {tuple(X.shape)}")
         return self._run(X, out=out)
 
+    def frames(self, x: torch.Tensor, starts, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Extension (batched dataset builder): transform the frames
+        ``x[starts[b] : starts[b] + n]`` of ONE 1-D buffer -- e.g. many recordings laid back to back, ``starts`` =
+        every frame of every recording (``framing.frame_starts``) -- in one call (``hssfsst_exec_list``).
+        ``x``: ``(T,)`` float32, CPU or cuda; ``starts``: int64 sequence / tensor (CPU, or on x's device).
+        Returns ``(len(starts), n, 2K)`` / ``(.., n, K)`` / complex64 ``(.., K, n)`` on x's device."""
+        x = self._as_f32(x)
+        if x.ndim != 1:
+            raise ValueError(f"FSST.frames: expected one 1-D buffer, got {tuple(x.shape)}")
+        if not isinstance(starts, torch.Tensor):
+            starts = torch.as_tensor(np.asarray(starts, dtype=np.int64))
+        starts = starts.to(torch.int64).contiguous()
+        if starts.ndim != 1:
+            raise ValueError("FSST.frames: starts must be 1-D")
+        B, T, n = int(starts.shape[0]), int(x.shape[0]), int(n)
+        if n < 1 or T < n:
+            raise ValueError(f"FSST.frames: frame length {n} does not fit a buffer of {T} samples")
+        if starts.is_cuda and (not x.is_cuda or starts.device != x.device):
+            starts = starts.cpu()
+        if B and not starts.is_cuda and (int(starts.min()) < 0 or int(starts.max()) > T - n):
+            raise ValueError(f"FSST.frames: a frame start lies outside [0, {T - n}]")
+        dev = self._device_index(x)
+        plan = self._plan(dev)
+        K, m = plan.K, plan.mode
+        if m == _lib.MODE_RAW:
+            shape, dt = (B, K, n), torch.complex64
+        elif m == _lib.MODE_ABS:
+            shape, dt = (B, n, K), torch.float32
+        else:
+            shape, dt = (B, n, 2 * K), torch.float32
+        if out is None:
+            out = torch.empty(shape, dtype=dt, device=x.device)
+        elif tuple(out.shape) != shape or out.dtype != dt or out.device != x.device or not out.is_contiguous():
+            raise ValueError(f"FSST.frames: out must be a contiguous {dt} tensor of shape {shape} on {x.device}")
+        if B == 0 or K == 0:
+            return out
+        on_dev = x.is_cuda
+        stream = torch.cuda.current_stream(dev).cuda_stream if on_dev else None
+        rc = _lib.lib().hssfsst_exec_list(plan.handle, ctypes.c_void_p(x.data_ptr()), T, ctypes.c_void_p(starts.data_ptr()),
+                                          1 if starts.is_cuda else 0, B, n, 1 if on_dev else 0,
+                                          ctypes.c_void_p(out.data_ptr()), 1 if on_dev else 0,
+                                          ctypes.c_void_p(stream) if stream else None)
+        _lib.check(rc, "hssfsst_exec_list")
+        return out
+
     def check(self, device_index: Optional[int] = None) -> bool:
         """Extension: waits for the device and raises ``RuntimeError`` if a kernel reported a failed internal wait;
         returns True when the plan's last ``stack`` call ran the fused (single-pass) kernel."""

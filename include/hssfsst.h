@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 201
+#define HSSFSST_VERSION 202
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -87,6 +87,15 @@ int hssfsst_exec_cols(hssfsst_plan* plan, const float* x, int64_t batch, int n, 
  * hssfsst_exec_cols(...) == hssfsst_exec_frames(..., x_stride = n, ...). */
 int hssfsst_exec_frames(hssfsst_plan* plan, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
                         int x_on_device, float* out, int out_on_device, void* stream);
+
+/* The same transform for a LIST of frames of one buffer: signal b = x[starts[b] .. starts[b] + n), 0 <= starts[b] <=
+ * x_len - n (checked when `starts` is host memory; a device array is trusted).  This is the batched form of the
+ * dataset loop hss/datasets/heart_sounds.py:155-169 over MANY recordings: the recordings sit back to back in `x`
+ * (one upload), `starts` lists every frame of every recording (hss/utils/preprocess.py:40-52), one call transforms
+ * them all: the frames are gathered into a dense batch on the device (8 kB per 2000-sample frame against 360 kB of
+ * features) and take the kernels of hssfsst_exec.  out: [batch][n][...] as hssfsst_exec. */
+int hssfsst_exec_list(hssfsst_plan* plan, const float* x, int64_t x_len, const int64_t* starts, int starts_on_device,
+                      int64_t batch, int n, int x_on_device, float* out, int out_on_device, void* stream);
 
 /* Device-side health of the plan's asynchronous work: waits for the device, then returns HSSFSST_EHIP if a bounded
  * wait inside a kernel gave up since the last check (never expected: it would mean the GPU did not keep the kernel's

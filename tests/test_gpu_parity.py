@@ -470,6 +470,44 @@ def test_stream_step_equals_separate_calls():
         a.step(torch.zeros(3, 3))
 
 
+@pytest.mark.parametrize("n,nwin", [(2000, 128), (333, 128), (500, 100), (300, 512)])
+def test_frame_list_equals_dense_batch(n, nwin):
+    """hssfsst_exec_list (frames of one buffer given by a list of starts: the batched dataset loop over many
+    recordings) == the dense batch of the same frames, bit for bit: every mode, host and device buffers, host and
+    device start lists, overlapping / repeated / unordered starts; bad starts are refused."""
+    from scipy.signal import get_window
+    from heart_sounds_segmentation_amd.corpus import build_features
+    rng = np.random.default_rng(n + nwin)
+    w = get_window(("kaiser", 0.5), nwin, fftbins=False)
+    T = 40 * n + 17
+    x = torch.from_numpy(synth.recording(T, seed=5))
+    starts = np.concatenate([[0, T - n, 7, 7], rng.integers(0, T - n + 1, size=300)]).astype(np.int64)
+    dense = torch.stack([x[s:s + n] for s in starts])
+    for kw in (dict(stack=True), dict(abs=True), dict()):
+        tf = FSST(1000, w, truncate_freq=BAND, **kw)
+        want = tf.batch(dense.cuda())
+        assert torch.equal(tf.frames(x.cuda(), starts, n), want), kw
+        assert torch.equal(tf.frames(x.cuda(), torch.from_numpy(starts).cuda(), n), want), kw
+        assert torch.equal(tf.frames(x, starts, n), want.cpu()), kw            # host buffer, staged by the library
+    tf = FSST(1000, w, truncate_freq=BAND, stack=True)
+    for bad in ([-1], [T - n + 1]):
+        with pytest.raises(ValueError):
+            tf.frames(x.cuda(), bad, n)
+        lst = (ctypes.c_int64 * 1)(*bad)
+        out = torch.empty((1, n, 2 * tf.band()[1]), dtype=torch.float32, device="cuda")
+        rc = _lib.lib().hssfsst_exec_list(tf._plan(0).handle, ctypes.c_void_p(x.cuda().data_ptr()), T, lst, 0, 1, n, 1,
+                                          ctypes.c_void_p(out.data_ptr()), 1, None)
+        assert rc == _lib.E_INVAL
+    assert tf.frames(x.cuda(), [], n).shape[0] == 0
+    if n == 2000:       # the grouped builder gives the same items whatever the group size
+        recs = [(torch.from_numpy(synth.recording(L, seed=s)), torch.randint(1, 5, (L,))) for s, L in enumerate((35000, 2500, 1999, 12345, 4000))]
+        a = build_features(recs, tf, windows_per_launch=1)
+        b = build_features(recs, tf)
+        assert len(a) == len(b) == 33 + 1 + 10 + 2
+        for (fa, la), (fb, lb) in zip(a, b):
+            assert torch.equal(fa, fb) and torch.equal(la, lb)
+
+
 def test_corpus_builder_and_end_to_end(oracle_mod):
     """the batched dataset builder yields what the reference's loop would
     (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,

@@ -26,15 +26,39 @@ res["C1_33_frames_batched_ms"] = round(timed(lambda: build_features([(rec, None)
 fr = torch.from_numpy(synth.pcg_windows(1, 2000)[0]).reshape(2000, 1)
 dt = min(timed(lambda: tf(fr), 200, 10) for _ in range(3))      # best of 3 rounds of 200 calls
 res["pcie_inclusive_single_window"] = {"ms_per_call": round(dt * 1e3, 4), "windows_per_s": round(1 / dt, 1)}
-# C3 stand-in on ONE GPU: 792 recordings x 35.5 k samples -> 26 136 windows, device-resident
+# C3 stand-in on ONE GPU: 792 recordings x 35.5 k samples -> 26 136 windows
 R = torch.from_numpy(synth.pcg_windows(8, 35500, seed=5)).cuda()
-from heart_sounds_segmentation_amd.framing import frame_batch
-def corpus():
+from heart_sounds_segmentation_amd.framing import frame_batch, frame_starts
+def corpus_per_recording():
     for r in range(792):
         tf.batch(frame_batch(R[r % 8], 1000, 2000))
-dt = timed(corpus, 2, 1)
-res["C3_standin_1gpu"] = {"recordings": 792, "windows": 792 * 33, "seconds": round(dt, 4), "windows_per_s": round(792 * 33 / dt, 1),
-                          "note": "one launch per recording (33 windows): launch-bound; bench.py batches 1024"}
+dt1 = timed(corpus_per_recording, 2, 1)
+# the same corpus as groups of 124 recordings (4092 windows) laid back to back: one hssfsst_exec_list call per group
+GROUP = 124
+big = torch.cat([R[r % 8] for r in range(GROUP)])
+st0 = torch.from_numpy(frame_starts(35500, 1000, 2000)[0])
+starts = torch.cat([st0 + 35500 * r for r in range(GROUP)]).cuda()
+outg = torch.empty((GROUP * 33, 2000, 44), dtype=torch.float32, device="cuda")
+def corpus_grouped():
+    done = 0
+    while done < 792:
+        g = min(GROUP, 792 - done)
+        tf.frames(big[: g * 35500], starts[: g * 33], 2000, out=outg[: g * 33])
+        done += g
+dt2 = timed(corpus_grouped, 3, 1)
+# host recordings -> features on the device through the product's builder (upload of every group included)
+recs_host = [(torch.from_numpy(synth.recording(35500, seed=100 + (r % 8))), None) for r in range(792)]
+t0 = time.perf_counter(); items = build_features(recs_host, tf, keep_on_device=True); torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+assert len(items) == 792 * 33
+del items
+res["C3_standin_1gpu"] = {"recordings": 792, "windows": 792 * 33,
+                          "per_recording_launches": {"seconds": round(dt1, 4), "windows_per_s": round(792 * 33 / dt1, 1),
+                                                     "note": "one launch per recording (33 windows): launch-bound"},
+                          "grouped_frame_lists": {"seconds": round(dt2, 4), "windows_per_s": round(792 * 33 / dt2, 1),
+                                                  "note": "7 hssfsst_exec_list calls of <= 4092 windows, device-resident"},
+                          "build_features_host_to_device": {"seconds": round(dt3, 4), "windows_per_s": round(792 * 33 / dt3, 1),
+                                                            "note": "corpus.build_features: host recordings -> device features, "
+                                                                    "Python list of 26 136 items included"}}
 # C4: 50 windows -> FSST -> BiLSTM(44 -> 2x240 -> 2x240 -> 4) inference
 head = SegmenterHead(44, 240, 50).cuda().eval()
 X50 = torch.from_numpy(synth.pcg_windows(50, 2000, seed=9)).cuda()
