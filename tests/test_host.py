@@ -153,3 +153,10 @@ def test_csv_ingest_matches_pandas(built_lib, tmp_path):
     assert ingest.parse_csv_bytes(b"Signals,Labels\n")[0].numel() == 0
     x2, y2 = ingest.parse_csv_bytes(b"Signals,Labels\r\n1.5,2.0\r\n\r\n-2e-3,4\n")
     assert x2.tolist() == [1.5, -0.0020000000949949026] and y2.tolist() == [2, 4]
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: __graft_entry__.build() compiles the library and the oracle and verifies
+    the ABI version against the header (a hard-coded number once broke it after an ABI bump)."""
+    import __graft_entry__ as g
+    g.build()
