@@ -261,7 +261,8 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below 1e-6 R are left to float32: they
 // cannot change a feature by 1e-4 of the largest feature wherever they land.  Large cells have tau ~ 1e-6 and are
 // practically never queued; the queue holds the small far-moving cells that float32 cannot place.
-constexpr int kTieQueue = 32;                // entries per wave and 16-frame group; overflow falls back to float32
+constexpr int kTieQueue = 64;                // entries per wave and 16-frame group; overflow falls back to float32
+constexpr int kTieCoop = 6;                  // up to this many queued cells the wave resolves them one by one, all lanes on one cell
 constexpr int kTieWords = 4 + 3 * kTieQueue; // [0] count, [4 + 3 e ..] = {bin | frame << 16, V.re, V.im}
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
 constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
@@ -342,6 +343,33 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
                                              const double* wtab, const double* twtab, int lane)
 {
     const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueue);
+    if (qn > kTieCoop) {
+        // many cells (tonal signals: every leakage bin of a frame is small and far-moving): ONE CELL PER LANE, the 4 nwin
+        // float64 multiply-adds of its bin in sequence (window pair: one address for the wave; twiddle: per lane from
+        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones
+        const bool act = lane < qn;
+        const int meta = act ? tq[4 + 3 * lane] : 0;
+        const int kpi = meta & 0xffff, jf = meta >> 16;
+        double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll 8
+        for (int n = 0; n < NWIN; ++n) {                    // (unrolled: eight table loads in flight)
+            const double x = static_cast<double>(xg[jf + n]);
+            const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+            const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+            const double xw = x * wd.x, xd = x * wd.y;
+            vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+            dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+        }
+        if (act) {
+            const double den = vr * vr + vi * vi;
+            double shift = (dr * vi - di * vr) / den;
+            if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
+            const double a = static_cast<double>(kpi) + shift;
+            const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+            const f2 V = {__int_as_float(tq[5 + 3 * lane]), __int_as_float(tq[6 + 3 * lane])};
+            move_source<NWIN>(disp_base + jf * LDF, flag, klo, K, kpi, static_cast<int>(static_cast<long long>(r)) & (NWIN - 1), V);
+        }
+    } else
     for (int e = 0; e < qn; ++e) {
         const int meta = __builtin_amdgcn_readfirstlane(tq[4 + 3 * e]);
         const int kpi = meta & 0xffff, jf = meta >> 16;

@@ -31,7 +31,14 @@ def main():
     nwin = int(os.environ.get("AB_NWIN", "128"))
     fs = float(os.environ.get("AB_FS", "1000"))
     w = np.ascontiguousarray(synth.kaiser_window(nwin, 0.5))
-    X = torch.from_numpy(synth.pcg_windows(B, 2000)).cuda()
+    kind = os.environ.get("AB_INPUT", "pcg")                       # pcg | noise | tone (on-bin: the tie path's worst case)
+    if kind == "tone":
+        xh = np.tile(np.cos(2 * np.pi * (16 * fs / nwin) * np.arange(2000) / fs).astype(np.float32), (B, 1))
+    elif kind == "noise":
+        xh = synth.noise_windows(B, 2000)
+    else:
+        xh = synth.pcg_windows(B, 2000)
+    X = torch.from_numpy(xh).cuda()
     outs, plans, Ls = [], [], []
     for path in libs:
         L = load(path)

@@ -32,6 +32,8 @@ for case in range(ncases):
     kind = rng.choice(["noise", "pcg"])
     X = synth.noise_windows(batch, n, seed=int(rng.integers(1 << 30))) if kind == "noise" else synth.pcg_windows(batch, n, fs=fs, seed=int(rng.integers(1 << 30)))
     scale = float(10.0 ** rng.integers(-3, 4)); X = (X * scale).astype(np.float32)
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):       # re-run ONE case of a sweep (same draws)
+        continue
     desc = f"case {case}: nwin={nwin} {wkind} fs={fs:g} n={n} batch={batch} mode={mode} band={band} {kind} x{scale:g}"
     try:
         tf = FSST(fs, w, truncate_freq=band, stack=(mode == "stack"), abs=(mode == "abs"))
