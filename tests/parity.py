@@ -4,9 +4,11 @@ Per signal:  max|out - ref| <= TOL * max|ref|  and  ||out - ref||_2 <= TOL * ||r
 the time columns that are NOT rounding-fragile.  A column is fragile when some source cell's
 reassignment coordinate lies within FRAG_EPS of a rounding tie in the fp64 oracle (SURVEY section 7
 "discontinuous rounding"; round 1 needed 1e-3 here and budgets of 3-25 % of the columns, since round 2
-the GPU path resolves such cells in float64 itself).  Fragile columns are counted and bounded, never silently dropped: the gate also fails
-if they exceed FRAG_BUDGET of all columns, and inside them the error must still be explainable by
-a moved cell (|err| bounded by twice the signal's largest feature).
+the GPU path resolves such cells in float64 itself).  Fragile columns are counted, never silently dropped: those of them
+that DIFFER from the oracle by more than TOL (a cell rounded the other way) are bounded by FRAG_BUDGET of all columns --
+a fragile column that agrees is just a column: tools/fuzz_parity.py seed 13 drew a signal with three of them, all within
+8e-8 of the oracle -- and inside them the error must still be explainable by a moved cell (|err| bounded by twice the
+signal's largest feature).
 """
 import numpy as np
 
@@ -36,11 +38,13 @@ def check(out, ref, halfdist, time_axis, tol=TOL, frag_eps=FRAG_EPS, frag_budget
     l2 = float(np.linalg.norm((o - r)[robust])) if robust.any() else 0.0
     l2ref = float(np.linalg.norm(r[robust])) if robust.any() else 0.0
     nfrag = int(fragile.sum())
+    # fragile columns that actually differ (a cell rounded the other way); a fragile column that agrees is just a column
+    nflip = int((err[fragile].max(axis=1) > tol * scale).sum()) if nfrag and err.shape[1] else 0
     res = dict(max_err=max_err, scale=scale, rel=max_err / scale if scale else 0.0,
-               rel_l2=l2 / l2ref if l2ref else 0.0, fragile=nfrag, n=n)
+               rel_l2=l2 / l2ref if l2ref else 0.0, fragile=nfrag, flipped=nflip, n=n)
     assert max_err <= tol * scale, f"{what}: max err {max_err:.3e} > {tol:g} * {scale:.3e} ({res})"
     assert l2 <= tol * l2ref, f"{what}: rel L2 {res['rel_l2']:.3e} > {tol:g} ({res})"
-    assert nfrag <= max(2, frag_budget * n), f"{what}: {nfrag}/{n} fragile columns exceed the budget"
+    assert nflip <= max(2, frag_budget * n), f"{what}: {nflip}/{n} fragile columns differ, over the budget ({nfrag} fragile)"
     if nfrag and err.shape[1]:
         # a flipped cell moves at most its own magnitude between two rows
         # a flipped cell moves at most one cell's magnitude (bounded by ~the signal's max) between rows

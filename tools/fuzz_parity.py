@@ -47,7 +47,15 @@ for case in range(ncases):
         for b in range(batch):
             if mode == "stack" and not np.isfinite(ref[b]).all():
                 continue                                  # degenerate statistics (constant block): reference gives NaN/inf too
-            r = parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=desc, )
+            r = parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=desc,
+                             frag_budget=float(os.environ.get("FUZZ_FRAG_BUDGET", parity.FRAG_BUDGET)))
+            if os.environ.get("FUZZ_ONLY"):               # diagnosis of one case: what the fragile columns look like
+                fr = np.asarray(hd[b]) < parity.FRAG_EPS
+                if fr.any():
+                    ax = 1 if mode == "raw" else 0
+                    e = np.abs(np.moveaxis(got[b], ax, 0) - np.moveaxis(ref[b], ax, 0)).reshape(len(fr), -1)
+                    print(f"    signal {b}: {int(fr.sum())} fragile columns, halfdist {np.asarray(hd[b])[fr]}, "
+                          f"max err there {e[fr].max():.3e} (scale {np.abs(ref[b]).max():.3e})")
             worst = max(worst, r["rel"])
     except AssertionError as e:
         msg = str(e)
