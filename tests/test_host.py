@@ -160,3 +160,41 @@ def test_graft_entry_build_runs():
     the ABI version against the header (a hard-coded number once broke it after an ABI bump)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_corpus_builder_groups_recordings_like_the_reference_loop():
+    """SURVEY section 8f row 1 on the CPU: corpus.build_features lays recordings back to back and hands ALL frames of a
+    group to one FSST.frames call; with a transform stand-in that returns the frames themselves, the items must be exactly
+    what the reference's loop yields (heart_sounds.py:155-169: skip < frame_len, frame_signal's L = floor((T-n)/stride)
+    frames -- one fewer than fit --, a single frame x[:n] when L <= 0, labels y - 1 framed alike), whatever the group size,
+    and a rank's share is a contiguous block of recordings."""
+    from heart_sounds_segmentation_amd.corpus import build_features
+    from heart_sounds_segmentation_amd.framing import frame_batch
+
+    class Identity:                                        # duck-typed FSST: features = the frame, as a (n, 1) block
+        calls = 0
+
+        def frames(self, x, starts, n, out=None):
+            Identity.calls += 1
+            return torch.stack([x[int(s):int(s) + n] for s in starts]).unsqueeze(-1)
+
+    rng = np.random.default_rng(4)
+    lens = (35000, 2500, 1999, 12345, 4000, 2000, 3000)
+    recs = [(torch.from_numpy(rng.standard_normal(L).astype(np.float32)), torch.from_numpy(rng.integers(1, 5, L))) for L in lens]
+    want = []
+    for x, y in recs:                                      # the reference loop, restated with the golden-pinned framing
+        if x.shape[0] < 2000:
+            continue
+        for fx, fy in zip(frame_batch(x, 1000, 2000), frame_batch(y - 1, 1000, 2000)):
+            want.append((fx, fy))
+    assert len(want) == 33 + 1 + 10 + 2 + 1 + 1
+    for wpl in (1, 40, 4096):
+        Identity.calls = 0
+        got = build_features(recs, Identity(), device="cpu", windows_per_launch=wpl)
+        assert len(got) == len(want)
+        assert Identity.calls == {1: 6, 40: 2, 4096: 1}[wpl]       # (groups close at >= wpl frames: 33+1+10 | 2+1+1)
+        for (gx, gy), (wx, wy) in zip(got, want):
+            assert torch.equal(gx[:, 0], wx) and torch.equal(gy, wy) and gy.dtype == torch.int64
+    parts = [build_features(recs, Identity(), device="cpu", rank=r, world=3) for r in range(3)]
+    flat = [it for p in parts for it in p]
+    assert len(flat) == len(want) and all(torch.equal(a[0][:, 0], b[0]) for a, b in zip(flat, want))
