@@ -288,23 +288,34 @@ __device__ __forceinline__ void wave_sync()
 // Moves a source k' -> row in a frame's displaced plane: the own plane holds V in the source's own column
 // (unconditional store), so V is taken out again there, added at `row` and -- conjugated -- at the negative-frequency
 // twin's row nwin - row (oracle/fsst_oracle.c step 6: two-sided cyclic scatter, one-sided rows kept).
-template <int NWIN>
-__device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V)
+template <int NWIN, bool LANE_OWNS = false>
+__device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V,
+                                            f2* own_cell = nullptr, bool stored = false)
 {
     auto add = [&](int idx, float re, float im) {
         float* q = reinterpret_cast<float*>(row_disp + idx);
         __hip_atomic_fetch_add(q, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(q + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        *flag = 1;                                      // this wave's displaced plane is no longer zero
     };
     if (row == kpi) return;                             // rounds back into its own row after all
     const int own = kpi - klo, idx = row - klo;
-    if (static_cast<unsigned>(own) < static_cast<unsigned>(K)) add(own, -V.x, -V.y);
-    if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) add(idx, V.x, V.y);
-    if (kpi != 0) {                                     // negative-frequency twin (k' = nwin/2 never moves)
-        const int idm = ((NWIN - row) & (NWIN - 1)) - klo;      // row -> nwin - row, value conj
-        if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) add(idm, V.x, -V.y);
+    const int idm = ((NWIN - row) & (NWIN - 1)) - klo;  // negative-frequency twin: row -> nwin - row, value conj
+    const bool in_row = static_cast<unsigned>(idx) < static_cast<unsigned>(K);
+    const bool in_twin = kpi != 0 && static_cast<unsigned>(idm) < static_cast<unsigned>(K);     // (k' = nwin/2 never moves)
+    bool touched = in_row | in_twin;
+    // taking V out of its own column: the lane that stored it a moment ago (LANE_OWNS; own_cell = its cell of the own
+    // plane, `stored` = wave-uniform: the source's stripe lies inside the stored cover, outside it there is nothing to
+    // take out) simply clears it; the float64 path, which runs later and for any lane's cell, subtracts it in the
+    // displaced plane
+    if constexpr (LANE_OWNS) {
+        if (stored) *own_cell = f2{0.0f, 0.0f};
+    } else if (static_cast<unsigned>(own) < static_cast<unsigned>(K)) {
+        add(own, -V.x, -V.y);
+        touched = true;
     }
+    if (in_row) add(idx, V.x, V.y);
+    if (in_twin) add(idm, V.x, -V.y);
+    if (touched) *flag = 1;                             // this wave's displaced plane is no longer zero: ONE write
 }
 
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
@@ -312,7 +323,7 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
 // group) in the displaced plane.
 template <int NWIN>
 __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* tq, int klo, int K, int kpi, int j,
-                                                 float num, float den, f2 V, float R2)
+                                                 float num, float den, f2 V, float R2, f2* own_cell, bool stored)
 {
     float shift = num * __builtin_amdgcn_rcpf(den);
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
@@ -332,7 +343,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
         }
     }
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    move_source<NWIN>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V);
+    move_source<NWIN, true>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
 }
 
 // The whole wave, after the group's spectra: every queued cell's bin of V and Vd' by a float64 DFT of its frame
@@ -435,8 +446,8 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
 #endif
     const bool ma = fabsf(dna.y) >= kStay * dna.x, mb = fabsf(dnb.y) >= kStay * dnb.x;
     if (ma | mb) {                                      // skipped when no lane moved (execz)
-        if (ma) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2);
-        if (mb) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2);
+        if (ma) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2, ownA, store);
+        if (mb) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2, ownB, store);
     }
 }
 

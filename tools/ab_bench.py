@@ -31,6 +31,8 @@ def main():
     nwin = int(os.environ.get("AB_NWIN", "128"))
     fs = float(os.environ.get("AB_FS", "1000"))
     w = np.ascontiguousarray(synth.kaiser_window(nwin, 0.5))
+    if os.environ.get("AB_WINDOW", "kaiser") == "hann":
+        w = np.ascontiguousarray(np.hanning(nwin).astype(np.float64))
     kind = os.environ.get("AB_INPUT", "pcg")                       # pcg | noise | tone (on-bin: the tie path's worst case)
     if kind == "tone":
         xh = np.tile(np.cos(2 * np.pi * (16 * fs / nwin) * np.arange(2000) / fs).astype(np.float32), (B, 1))
