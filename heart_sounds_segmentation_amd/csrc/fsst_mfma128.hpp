@@ -328,7 +328,11 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
     float shift = num * __builtin_amdgcn_rcpf(den);
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
     const float a = static_cast<float>(kpi) + shift;
-    const float fr = a - floorf(a) - 0.5f, s1 = 1.0f + fabsf(shift);
+    float fr = a - floorf(a) - 0.5f;
+    const float s1 = 1.0f + fabsf(shift);
+    // (opaque: otherwise the two independent product chains below are packed into v_pk_mul_f32 pairs whose operand
+    //  shuffles and hazard nops cost more than the five plain multiplies)
+    asm volatile("" : "+v"(fr));
 #ifdef HSS_NO_TIES                                       // development: cost of the tie path (tools/ab_bench.py)
     if (false) {
 #else
