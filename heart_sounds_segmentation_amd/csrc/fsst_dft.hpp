@@ -23,6 +23,11 @@
 
 namespace hssfsst {
 
+// this kernel's rounding-tie queue: {bin | frame << 16, V.re, V.im} per entry (the MFMA kernel's is more compact)
+constexpr int kDftTieQueue = 64;
+constexpr int kDftTieWords = 4 + 3 * kDftTieQueue;
+
+
 struct DftParams {
     const float* x;       // [batch][n] (signal starts xstride apart)
     float* out;
@@ -43,7 +48,7 @@ struct DftParams {
 __host__ __device__ constexpr int dft_xs_floats(int nk4, int G = 1) { return ((16 * G + 4 * nk4 + 3) / 4) * 4; }
 __host__ __device__ constexpr int dft_wave_lds_floats(int nk4, int K, int G = 1)
 {
-    return dft_xs_floats(nk4, G) + 2 * 16 * G * plane_ldf(K) + 4 + kTieWords;
+    return dft_xs_floats(nk4, G) + 2 * 16 * G * plane_ldf(K) + 4 + kDftTieWords;
 }
 
 // One wave = one tile of G groups at a time (grid-stride over batch x tiles); blockDim = 64 x (waves that fit the LDS).
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
                     bool queued = false;
                     if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {
                         const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (slot < kTieQueue) {
+                        if (slot < kDftTieQueue) {
                             tq[4 + 3 * slot] = kp | (jq << 16);
                             tq[5 + 3 * slot] = __float_as_int(vr);
                             tq[6 + 3 * slot] = __float_as_int(vi);
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
         }
         wave_sync();
         // rounding ties: float64 DFT of the one bin, all lanes (fsst_mfma128.hpp "Rounding ties")
-        const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueue);
+        const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kDftTieQueue);
         for (int e = 0; e < qn; ++e) {
             const int meta = __builtin_amdgcn_readfirstlane(tq[4 + 3 * e]);
             const int kp = meta & 0xffff, jf = meta >> 16;

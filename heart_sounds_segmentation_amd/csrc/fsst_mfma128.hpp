@@ -261,9 +261,13 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below 1e-6 R are left to float32: they
 // cannot change a feature by 1e-4 of the largest feature wherever they land.  Large cells have tau ~ 1e-6 and are
 // practically never queued; the queue holds the small far-moving cells that float32 cannot place.
-constexpr int kTieQueue = 64;                // entries per wave and 16-frame group; overflow falls back to float32
+// Two queues per wave and 16-frame group (overflow falls back to float32 rounding): cells whose float32 V sits in the
+// own plane (sources inside the stored cover: the rows next to the band, the cells that matter most) take ONE word,
+// bin | frame << 16, and their V is read back -- and cleared -- there; sources outside the cover carry their V along
+constexpr int kTieQueueIn = 120;             // [4 .. 4 + 120): bin | frame << 16
+constexpr int kTieQueueOut = 24;             // [4 + 120 ..): {bin | frame << 16, V.re, V.im}
 constexpr int kTieCoop = 6;                  // up to this many queued cells the wave resolves them one by one, all lanes on one cell
-constexpr int kTieWords = 4 + 3 * kTieQueue; // [0] count, [4 + 3 e ..] = {bin | frame << 16, V.re, V.im}
+constexpr int kTieWords = 4 + kTieQueueIn + 3 * kTieQueueOut;     // [0] in-cover count, [1] out-of-cover count
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
 constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
                                              // random configurations 1.4-1.8x over the gate: tools/fuzz_parity.py 1000 3)
@@ -338,12 +342,21 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 #else
     if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
 #endif
-        const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (slot < kTieQueue) {
-            tq[4 + 3 * slot] = kpi | (j << 16);
-            tq[5 + 3 * slot] = __float_as_int(V.x);
-            tq[6 + 3 * slot] = __float_as_int(V.y);
-            return;
+        if (stored) {                                   // (wave-uniform) the float32 V is in the own plane: one word
+            const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < kTieQueueIn) {
+                tq[4 + slot] = kpi | (j << 16);
+                return;
+            }
+        } else {
+            const int slot = __hip_atomic_fetch_add(tq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < kTieQueueOut) {
+                int* q = tq + 4 + kTieQueueIn + 3 * slot;
+                q[0] = kpi | (j << 16);
+                q[1] = __float_as_int(V.x);
+                q[2] = __float_as_int(V.y);
+                return;
+            }
         }
     }
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
@@ -352,41 +365,62 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 
 // The whole wave, after the group's spectra: every queued cell's bin of V and Vd' by a float64 DFT of its frame
 // (xg = the group's first frame in the LDS tile; wtab[n] = {w, dw'}[n], twtab[m] = {cos, sin}(2 pi m / nwin), float64),
-// the float64 coordinate k' - Im(Vd'/V) rounded half away from zero, then the move.
+// the float64 coordinate k' - Im(Vd'/V) rounded half away from zero, then the move of the float32 V: read back from --
+// and cleared in -- the source's own column (in-cover queue: columns [cov0, ..) of the own plane, leading dimension
+// OLD), or carried by the entry (out-of-cover queue: no own cell, none in the band).  Entry e of the combined list:
+// e < n_in -> in-cover queue, else out-of-cover queue.
+template <int NWIN>
+__device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                            f2* own_base, int OLD, int cov0, int kpi, int jf, double vr, double vi, double dr, double di)
+{
+    const double den = vr * vr + vi * vi;
+    double shift = (dr * vi - di * vr) / den;
+    if (!(fabs(shift) <= 1.0e6)) shift = 0.0;           // V == 0 or absurd -> 0 (fsst.m: ~isfinite)
+    const double a = static_cast<double>(kpi) + shift;
+    const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+    const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
+    if (e < n_in) {
+        f2* cell = own_base + jf * OLD + (kpi - cov0);
+        const f2 V = *cell;
+        move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, V, cell, true);
+    } else {
+        const int* q = tq + 4 + kTieQueueIn + 3 * (e - n_in);
+        move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, f2{__int_as_float(q[1]), __int_as_float(q[2])}, nullptr, false);
+    }
+}
+
 template <int NWIN>
 __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                             f2* own_base, int OLD, int cov0,
                                              const double* wtab, const double* twtab, int lane)
 {
-    const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueue);
+    const int n_in = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueueIn);
+    const int qn = n_in + min(__builtin_amdgcn_readfirstlane(tq[1]), kTieQueueOut);
+    auto meta_of = [&](int e) { return (e < n_in) ? tq[4 + e] : tq[4 + kTieQueueIn + 3 * (e - n_in)]; };
     if (qn > kTieCoop) {
         // many cells (tonal signals: every leakage bin of a frame is small and far-moving): ONE CELL PER LANE, the 4 nwin
         // float64 multiply-adds of its bin in sequence (window pair: one address for the wave; twiddle: per lane from
-        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones
-        const bool act = lane < qn;
-        const int meta = act ? tq[4 + 3 * lane] : 0;
-        const int kpi = meta & 0xffff, jf = meta >> 16;
-        double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones; up to three rounds of 64
+        for (int base = 0; base < qn; base += 64) {
+            const int e = base + lane;
+            const bool act = e < qn;
+            const int meta = act ? meta_of(e) : 0;
+            const int kpi = meta & 0xffff, jf = meta >> 16;
+            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
 #pragma unroll 8
-        for (int n = 0; n < NWIN; ++n) {                    // (unrolled: eight table loads in flight)
-            const double x = static_cast<double>(xg[jf + n]);
-            const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-            const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
-            const double xw = x * wd.x, xd = x * wd.y;
-            vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-            dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
-        }
-        if (act) {
-            const double den = vr * vr + vi * vi;
-            double shift = (dr * vi - di * vr) / den;
-            if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
-            const double a = static_cast<double>(kpi) + shift;
-            const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
-            const f2 V = {__int_as_float(tq[5 + 3 * lane]), __int_as_float(tq[6 + 3 * lane])};
-            move_source<NWIN>(disp_base + jf * LDF, flag, klo, K, kpi, static_cast<int>(static_cast<long long>(r)) & (NWIN - 1), V);
+            for (int n = 0; n < NWIN; ++n) {                // (unrolled: eight table loads in flight)
+                const double x = static_cast<double>(xg[jf + n]);
+                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+                const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+                const double xw = x * wd.x, xd = x * wd.y;
+                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+            }
+            if (act) resolve_one<NWIN>(tq, e, n_in, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, kpi, jf, vr, vi, dr, di);
         }
     } else
     for (int e = 0; e < qn; ++e) {
-        const int meta = __builtin_amdgcn_readfirstlane(tq[4 + 3 * e]);
+        const int meta = __builtin_amdgcn_readfirstlane(meta_of(e));
         const int kpi = meta & 0xffff, jf = meta >> 16;
         double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
 #pragma unroll
@@ -403,17 +437,9 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
             vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
             dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
         }
-        if (lane == 0) {
-            const double den = vr * vr + vi * vi;
-            double shift = (dr * vi - di * vr) / den;
-            if (!(fabs(shift) <= 1.0e6)) shift = 0.0;   // V == 0 or absurd -> 0 (fsst.m: ~isfinite)
-            const double a = static_cast<double>(kpi) + shift;
-            const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
-            const f2 V = {__int_as_float(tq[5 + 3 * e]), __int_as_float(tq[6 + 3 * e])};
-            move_source<NWIN>(disp_base + jf * LDF, flag, klo, K, kpi, static_cast<int>(static_cast<long long>(r)) & (NWIN - 1), V);
-        }
+        if (lane == 0) resolve_one<NWIN>(tq, e, n_in, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, kpi, jf, vr, vi, dr, di);
     }
-    if (lane == 0) tq[0] = 0;
+    if (lane == 0) { tq[0] = 0; tq[1] = 0; }
 }
 
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane == 0) { *flag = 0; tq[0] = 0; }
+    if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
     if constexpr (FUSED) {
         if (wv == 0) {
@@ -814,9 +840,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
         wave_sync();
         // one LDS round trip for both per-group flags (dirty displaced plane, queued rounding ties)
         int f_dirty = flag[0];
-        const int f_ties = tq[0];
+        const int f_ties = tq[0] | tq[1];
         if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
-            resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, p.wtab, p.twtab, lane_o);
+            resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, p.wtab, p.twtab, lane_o);
             wave_sync();
             f_dirty = flag[0];
         }
