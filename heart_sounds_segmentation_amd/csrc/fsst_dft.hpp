@@ -24,7 +24,7 @@
 namespace hssfsst {
 
 // this kernel's rounding-tie queue: {bin | frame << 16, V.re, V.im} per entry (the MFMA kernel's is more compact)
-constexpr int kDftTieQueue = 64;
+constexpr int kDftTieQueue = 256;
 constexpr int kDftTieWords = 4 + 3 * kDftTieQueue;
 
 
@@ -155,6 +155,36 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
         wave_sync();
         // rounding ties: float64 DFT of the one bin, all lanes (fsst_mfma128.hpp "Rounding ties")
         const int qn = min(__builtin_amdgcn_readfirstlane(tq[0]), kDftTieQueue);
+        if (qn > 6) {
+            // many cells (tonal input): one cell per lane, its N taps in sequence (fsst_mfma128.hpp resolve_ties)
+            for (int base = 0; base < qn; base += 64) {
+                const int e = base + lane;
+                const bool act = e < qn;
+                const int meta = act ? tq[4 + 3 * e] : 0;
+                const int kp = meta & 0xffff, jf = meta >> 16;
+                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+                int ti = 0;                                      // (kp * nn) mod N, kept incrementally
+#pragma unroll 4
+                for (int nn = 0; nn < N; ++nn) {
+                    const double x = static_cast<double>(xs[jf + nn]);
+                    const double2 wd = reinterpret_cast<const double2*>(p.wtab)[nn];
+                    const double2 cs = reinterpret_cast<const double2*>(p.twtab)[ti];
+                    ti += kp; if (ti >= N) ti -= N;
+                    const double xw = x * wd.x, xd = x * wd.y;
+                    vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                    dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                }
+                if (act) {
+                    double shift = (dr * vi - di * vr) / (vr * vr + vi * vi);
+                    if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
+                    const double a = static_cast<double>(kp) + shift;
+                    const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+                    long long row = static_cast<long long>(r) % N;
+                    if (row < 0) row += N;
+                    land(jf, kp, static_cast<int>(row), __int_as_float(tq[5 + 3 * e]), __int_as_float(tq[6 + 3 * e]));
+                }
+            }
+        } else
         for (int e = 0; e < qn; ++e) {
             const int meta = __builtin_amdgcn_readfirstlane(tq[4 + 3 * e]);
             const int kp = meta & 0xffff, jf = meta >> 16;

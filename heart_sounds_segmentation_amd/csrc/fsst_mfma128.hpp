@@ -264,10 +264,11 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // Two queues per wave and 16-frame group (overflow falls back to float32 rounding): cells whose float32 V sits in the
 // own plane (sources inside the stored cover: the rows next to the band, the cells that matter most) take ONE word,
 // bin | frame << 16, and their V is read back -- and cleared -- there; sources outside the cover carry their V along
-constexpr int kTieQueueIn = 120;             // [4 .. 4 + 120): bin | frame << 16
-constexpr int kTieQueueOut = 24;             // [4 + 120 ..): {bin | frame << 16, V.re, V.im}
+// (a group of a longer window has proportionally more uncertain cells on a tonal input: 504 for nwin 512, where LDS is not what limits the waves; 120 for 128 and 256)
+__host__ __device__ constexpr int tie_queue_in(int nwin) { return nwin >= 512 ? 504 : 120; }   // [4 ..): bin | frame << 16
+constexpr int kTieQueueOut = 24;             // behind them: {bin | frame << 16, V.re, V.im}
 constexpr int kTieCoop = 6;                  // up to this many queued cells the wave resolves them one by one, all lanes on one cell
-constexpr int kTieWords = 4 + kTieQueueIn + 3 * kTieQueueOut;     // [0] in-cover count, [1] out-of-cover count
+__host__ __device__ constexpr int tie_words(int nwin) { return 4 + tie_queue_in(nwin) + 3 * kTieQueueOut; }   // [0] in-cover count, [1] out-of-cover count
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
 constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
                                              // random configurations 1.4-1.8x over the gate: tools/fuzz_parity.py 1000 3)
@@ -279,7 +280,7 @@ constexpr float kTieFloor2 = 1.0e-12f;       // (1e-6)^2: cells with |V|^2 below
 __host__ __device__ constexpr int wave_lds_floats(int fpw, int klo, int K, int rq = 8, int nt = 16)
 {
     return ((fpw + nt * rq - 1 + 3) / 4) * 4 + 2 * 16 * (own_ld(klo, K, rq) + plane_ldf(K)) + 4   // + dirty flag
-           + kTieWords;                                                                              // + tie queue
+           + tie_words(nt * rq);                                                                     // + tie queues
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -342,16 +343,17 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 #else
     if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
 #endif
+        constexpr int QI = tie_queue_in(NWIN);          // (constant context: never a call)
         if (stored) {                                   // (wave-uniform) the float32 V is in the own plane: one word
             const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < kTieQueueIn) {
+            if (slot < QI) {
                 tq[4 + slot] = kpi | (j << 16);
                 return;
             }
         } else {
             const int slot = __hip_atomic_fetch_add(tq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < kTieQueueOut) {
-                int* q = tq + 4 + kTieQueueIn + 3 * slot;
+                int* q = tq + 4 + QI + 3 * slot;
                 q[0] = kpi | (j << 16);
                 q[1] = __float_as_int(V.x);
                 q[2] = __float_as_int(V.y);
@@ -384,7 +386,8 @@ __device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_b
         const f2 V = *cell;
         move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, V, cell, true);
     } else {
-        const int* q = tq + 4 + kTieQueueIn + 3 * (e - n_in);
+        constexpr int QI = tie_queue_in(NWIN);
+        const int* q = tq + 4 + QI + 3 * (e - n_in);
         move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, f2{__int_as_float(q[1]), __int_as_float(q[2])}, nullptr, false);
     }
 }
@@ -394,13 +397,14 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
                                              f2* own_base, int OLD, int cov0,
                                              const double* wtab, const double* twtab, int lane)
 {
-    const int n_in = min(__builtin_amdgcn_readfirstlane(tq[0]), kTieQueueIn);
+    constexpr int QI = tie_queue_in(NWIN);
+    const int n_in = min(__builtin_amdgcn_readfirstlane(tq[0]), QI);
     const int qn = n_in + min(__builtin_amdgcn_readfirstlane(tq[1]), kTieQueueOut);
-    auto meta_of = [&](int e) { return (e < n_in) ? tq[4 + e] : tq[4 + kTieQueueIn + 3 * (e - n_in)]; };
+    auto meta_of = [&](int e) { return (e < n_in) ? tq[4 + e] : tq[4 + QI + 3 * (e - n_in)]; };
     if (qn > kTieCoop) {
         // many cells (tonal signals: every leakage bin of a frame is small and far-moving): ONE CELL PER LANE, the 4 nwin
         // float64 multiply-adds of its bin in sequence (window pair: one address for the wave; twiddle: per lane from
-        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones; up to three rounds of 64
+        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones; rounds of 64
         for (int base = 0; base < qn; base += 64) {
             const int e = base + lane;
             const bool act = e < qn;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
-    int* tq = flag + 4;                                                       // rounding-tie queue (kTieWords)
+    int* tq = flag + 4;                                                       // rounding-tie queues (tie_words(NWIN))
 
     // shared MFMA A operand, regrouped so that a lane reads all k-steps of a tap with one LDS instruction:
     // global [pass * 16 + tap][k-step][lane]  ->  LDS [pass * 16 + tap][lane][k-step]

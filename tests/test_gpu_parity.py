@@ -508,16 +508,19 @@ def test_frame_list_equals_dense_batch(n, nwin):
             assert torch.equal(fa, fb) and torch.equal(la, lb)
 
 
+@pytest.mark.parametrize("nwin", [128, 100, 512])
 @pytest.mark.parametrize("wname", ["kaiser0.5", "hann", "blackman"])
-def test_pure_tones_heavy_windows(oracle_mod, wname):
+def test_pure_tones_heavy_windows(oracle_mod, wname, nwin):
     """Pure sinusoids (on a bin, off a bin, 50 Hz), alone / amplitude-modulated / with a harmonic, under Kaiser(0.5), Hann and
     Blackman windows: every leakage bin of every frame is small against its frame's spectrum and moves by tens of bins,
     so nearly every cell is a rounding float32 cannot call -- the rounding-tie queues run full in every group (a Hann
-    window off a bin missed the gate, 1.2e-4, while the queue held 64 cells per group; 5.5e-5 with 120 + 24)."""
+    window off a bin missed the gate, 1.2e-4, while the queue held 64 cells per group; 5.5e-5 with 120 + 24).  nwin 512
+    (504 + 24 cells; with 120 + 24 Hann on a bin was 2.5e-4) and nwin 100 (the any-length kernel: 256 cells, one per lane;
+    with 64 cooperative ones Blackman on a bin was 6.7e-4) are the same story."""
     from scipy.signal import get_window
     fs, n = 1000.0, 2000
     t = np.arange(n) / fs
-    w = get_window(("kaiser", 0.5), 128, fftbins=False) if wname == "kaiser0.5" else get_window(wname, 128, fftbins=False)
+    w = get_window(("kaiser", 0.5), nwin, fftbins=False) if wname == "kaiser0.5" else get_window(wname, nwin, fftbins=False)
     for f0 in (125.0, 117.3, 50.0):
         X = np.stack([np.cos(2 * np.pi * f0 * t), np.cos(2 * np.pi * f0 * t + 0.7) * (1 + 0.3 * np.sin(2 * np.pi * 3 * t)),
                       np.cos(2 * np.pi * f0 * t) + 0.5 * np.cos(2 * np.pi * 2.2 * f0 * t)]).astype(np.float32)
@@ -526,7 +529,7 @@ def test_pure_tones_heavy_windows(oracle_mod, wname):
             got = tf.batch(torch.from_numpy(X).cuda()).cpu().numpy()
             ref, hd = oracle_mod.features(X, fs, w, BAND, mode, return_halfdist=True)
             for b in range(3):
-                parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=f"{wname} tone {f0} {mode} sig{b}")
+                parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=f"{wname}({nwin}) tone {f0} {mode} sig{b}")
 
 
 def test_corpus_builder_and_end_to_end(oracle_mod):

@@ -4,10 +4,12 @@ import oracle
 from heart_sounds_segmentation_amd import FSST, synth
 from tests import parity
 from scipy.signal import get_window
+import os
 fs, n = 1000.0, 2000
+NW = int(os.environ.get("TP_NWIN", "128"))
 t = np.arange(n) / fs
 for wname in ("kaiser0.5", "hann", "blackman"):
-    w = get_window(("kaiser", 0.5), 128, fftbins=False) if wname == "kaiser0.5" else get_window(wname, 128, fftbins=False)
+    w = get_window(("kaiser", 0.5), NW, fftbins=False) if wname == "kaiser0.5" else get_window(wname, NW, fftbins=False)
     for f0, label in ((125.0, "on-bin"), (117.3, "off-bin"), (50.0, "50 Hz")):
         X = np.stack([np.cos(2 * np.pi * f0 * t), np.cos(2 * np.pi * f0 * t + 0.7) * (1 + 0.3 * np.sin(2 * np.pi * 3 * t)),
                       np.cos(2 * np.pi * f0 * t) + 0.5 * np.cos(2 * np.pi * 2.2 * f0 * t)]).astype(np.float32)
