@@ -262,13 +262,14 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // cannot change a feature by 1e-4 of the largest feature wherever they land.  Large cells have tau ~ 1e-6 and are
 // practically never queued; the queue holds the small far-moving cells that float32 cannot place.
 // Two queues per wave and 16-frame group (overflow falls back to float32 rounding): cells whose float32 V sits in the
-// own plane (sources inside the stored cover: the rows next to the band, the cells that matter most) take ONE word,
-// bin | frame << 16, and their V is read back -- and cleared -- there; sources outside the cover carry their V along
-// (a group of a longer window has proportionally more uncertain cells on a tonal input: 504 for nwin 512, where LDS is not what limits the waves; 120 for 128 and 256)
-__host__ __device__ constexpr int tie_queue_in(int nwin) { return nwin >= 512 ? 504 : 120; }   // [4 ..): bin | frame << 16
+// own plane (sources inside the stored cover: the rows next to the band, the cells that matter most) take 16 bits,
+// bin | frame << 9, and their V is read back -- and cleared -- there; sources outside the cover carry their V along
+// (a group of a longer window has proportionally more uncertain cells on a tonal input: 1008 for nwin 512, where LDS is not what
+//  limits the waves; 240 for 128 and 256)
+__host__ __device__ constexpr int tie_queue_in(int nwin) { return nwin >= 512 ? 1008 : 240; }  // [4 ..): 16-bit entries, bin | frame << 9
 constexpr int kTieQueueOut = 24;             // behind them: {bin | frame << 16, V.re, V.im}
 constexpr int kTieCoop = 6;                  // up to this many queued cells the wave resolves them one by one, all lanes on one cell
-__host__ __device__ constexpr int tie_words(int nwin) { return 4 + tie_queue_in(nwin) + 3 * kTieQueueOut; }   // [0] in-cover count, [1] out-of-cover count
+__host__ __device__ constexpr int tie_words(int nwin) { return 4 + tie_queue_in(nwin) / 2 + 3 * kTieQueueOut; }   // [0] in-cover count, [1] out-of-cover count
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
 constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
                                              // random configurations 1.4-1.8x over the gate: tools/fuzz_parity.py 1000 3)
@@ -347,13 +348,13 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
         if (stored) {                                   // (wave-uniform) the float32 V is in the own plane: one word
             const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < QI) {
-                tq[4 + slot] = kpi | (j << 16);
+                reinterpret_cast<unsigned short*>(tq + 4)[slot] = static_cast<unsigned short>(kpi | (j << 9));
                 return;
             }
         } else {
             const int slot = __hip_atomic_fetch_add(tq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < kTieQueueOut) {
-                int* q = tq + 4 + QI + 3 * slot;
+                int* q = tq + 4 + QI / 2 + 3 * slot;
                 q[0] = kpi | (j << 16);
                 q[1] = __float_as_int(V.x);
                 q[2] = __float_as_int(V.y);
@@ -387,7 +388,7 @@ __device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_b
         move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, V, cell, true);
     } else {
         constexpr int QI = tie_queue_in(NWIN);
-        const int* q = tq + 4 + QI + 3 * (e - n_in);
+        const int* q = tq + 4 + QI / 2 + 3 * (e - n_in);
         move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, f2{__int_as_float(q[1]), __int_as_float(q[2])}, nullptr, false);
     }
 }
@@ -400,7 +401,13 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
     constexpr int QI = tie_queue_in(NWIN);
     const int n_in = min(__builtin_amdgcn_readfirstlane(tq[0]), QI);
     const int qn = n_in + min(__builtin_amdgcn_readfirstlane(tq[1]), kTieQueueOut);
-    auto meta_of = [&](int e) { return (e < n_in) ? tq[4 + e] : tq[4 + QI + 3 * (e - n_in)]; };
+    auto meta_of = [&](int e) -> int {                 // bin | frame << 16 of entry e of the combined list
+        if (e < n_in) {
+            const int m = reinterpret_cast<const unsigned short*>(tq + 4)[e];
+            return (m & 0x1ff) | ((m >> 9) << 16);
+        }
+        return tq[4 + QI / 2 + 3 * (e - n_in)];
+    };
     if (qn > kTieCoop) {
         // many cells (tonal signals: every leakage bin of a frame is small and far-moving): ONE CELL PER LANE, the 4 nwin
         // float64 multiply-adds of its bin in sequence (window pair: one address for the wave; twiddle: per lane from
