@@ -306,14 +306,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // the FLOAT32 sums small against the spread (a plain float32 sum x^2 loses the variance when mean^2 >> variance,
 // e.g. a DC-offset recording with a band that contains row 0).  From there on everything is float64: a piece's
 // moments about zero  sum x = n p + S1,  sum x^2 = S2 + p (2 S1 + n p)  are exact to 1e-16 and are simply added up
-// -- in a FIXED order: blocks of 16 consecutive pieces sequentially, then lane (block % 16) over blocks c, c + 16, ...,
+// -- in a FIXED order: blocks of kStatBlock (4) consecutive pieces sequentially, then lane (block % 16) over blocks c, c + 16, ...,
 // then a butterfly over the 16 block lanes -- so the statistics are run-to-run deterministic, independent of which
 // wave produced which partial, and identical whether the sums are formed here (two-kernel path) or inside the fused
 // kernel of fsst_mfma128.hpp, whose teams add their pieces in exactly this order.  The float64 cancellation in
 // sum x^2 - (sum x)^2 / N is harmless whenever the float32 features themselves still resolve the spread.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPartFloats = 8;
-constexpr int kStatBlock = 16;             // pieces per block of the summation order
+constexpr int kStatBlock = 4;              // pieces per block of the summation order (= the groups of one 64-frame chunk of
+                                           // the team kernel, which publishes one float64 block sum per chunk)
 
 // quantity q of a piece: 0 = sum re, 1 = sum re^2, 2 = sum im, 3 = sum im^2 (s1, s2, pivot of that block of columns)
 __device__ __forceinline__ double piece_moment(int q, double s1, double s2, double piv, double cnt)
@@ -338,12 +339,11 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off, int lane)
 // (blk % 16, q) for blk = lane >> 2, (lane >> 2) + 16, ...  total = number of elements per block of columns (K * ncols).
 // Returns {mean_re, 1/std_re, mean_im, 1/std_im} (float32, like the reference's float32 tensors; a zero variance gives
 // 1/0 = inf and the z-score (v - mean) * inf = NaN for every element, as torch's 0/0).
-template <class BlockSum>
-__device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum, int lane)
+// stats_finish: the part after the per-lane accumulation (lane (blk % 16, q) holds the sum of its blocks' quantity q);
+// split off so that the team kernel of fsst_team128.hpp, whose block sums arrive through HBM mailboxes, runs the very same
+// instructions on the very same numbers as the two-kernel path.
+__device__ __forceinline__ float4 stats_finish(double acc, double total, int lane)
 {
-    const int q = lane & 3;
-    double acc = 0.0;
-    for (int blk = lane >> 2; blk < nblocks; blk += 16) acc += block_sum(blk, q);
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) {
         const double o = shfl_xor_f64(acc, off, lane);
@@ -360,6 +360,14 @@ __device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, B
     const double vr = fma(-sx_re, mr, sxx_re) / (total - 1.0), vi = fma(-sx_im, mi, sxx_im) / (total - 1.0);
     return make_float4(static_cast<float>(mr), 1.0f / static_cast<float>(sqrt(vr)),
                        static_cast<float>(mi), 1.0f / static_cast<float>(sqrt(vi)));
+}
+template <class BlockSum>
+__device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum, int lane)
+{
+    const int q = lane & 3;
+    double acc = 0.0;
+    for (int blk = lane >> 2; blk < nblocks; blk += 16) acc += block_sum(blk, q);
+    return stats_finish(acc, total, lane);
 }
 
 // The two-kernel path: partials in HBM, [nparts][kPartFloats]; fpp = frames per piece.

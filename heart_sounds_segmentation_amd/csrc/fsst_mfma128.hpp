@@ -518,7 +518,7 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
                                                    // waits give up at once (LDS word `dead`), so a broken launch ends fast
 
 template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false>
-__global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_core128_kernel(Core128Params p)
+__global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
 {
     static_assert(!FUSED || FAST, "the fused z-score rides on the wide-store epilogue");
     constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : 2)) void fsst_co
             if (__builtin_amdgcn_readfirstlane(have) == epoch) break;
             if (spins >= kSpinLimit || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 if (lane == 0) {
-                    __hip_atomic_store((gu32*)(p.status), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((gu32*)(p.status), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 break;

@@ -1,0 +1,550 @@
+// fsst_team128.hpp -- the canonical-window transform with the z-score of FSST._stack_real_imag
+// (/root/reference/hss/transforms/synchrosqueeze.py:78-85) done IN REGISTERS: every feature is written to HBM exactly
+// once, already normalised (algorithmic traffic: 8 000 B in + 352 000 B out per 2000-sample window, nothing else).
+//
+// Why this shape.  The z-score needs the mean / unbiased std of a whole signal's (n, 2K) feature block before its first
+// element can be stored.  Round 2 kept the block in HBM (written, read back by the same CU, overwritten: 2.94x the
+// algorithmic traffic, profiles/r02_pmc.json) because neither the L2 (profiles/r02_fused_team_variant.txt) nor the LDS of
+// 16 resident waves can hold it.  Measured this round (profiles/r03_occupancy.txt): the transform loses only 6 % at TWO
+// waves per SIMD instead of four -- and two waves per SIMD own 256 VGPRs each.  So:
+//   * one persistent block of 8 waves per CU; a TEAM of T CUs of one XCD shares each signal: the signal's 64-frame chunks
+//     (4 groups of 16 frames = one tile = one block of the statistics' summation order, kStatBlock) are dealt round-robin
+//     to the team's CUs, rotated by the signal index so that the short last chunk does not always hit the same CU;
+//   * a wave transforms a chunk exactly like fsst_core128_kernel, but the group's (16, 2K) image goes from the LDS plane
+//     into 12 VGPRs per group instead of to HBM; the four statistics partials of the chunk are folded, in float64 and in
+//     the order of signal_stats(), into ONE block sum {sum re, sum re^2, sum im, sum im^2} that the wave publishes in the
+//     team's mailbox (8 tagged 8-byte words, relaxed agent-scope atomics: no fence, no cache-wide write-back);
+//   * the wave then transforms its NEXT chunk (second register set) -- that is the time in which the team-mates publish
+//     theirs -- and only afterwards collects the signal's block sums (one tagged 16-byte read per lane and 16 blocks),
+//     runs stats_finish() on them (the very instructions of the two-kernel path: bit-identical statistics), z-scores
+//     the first chunk's registers and streams them out.  A wave never waits while it still has work it may start.
+// Only statistics cross CUs (64 B per chunk); nothing relies on a cache keeping anything.
+//
+// Progress.  Every CU's work list is signal-major and identical in shape, a wave publishes a chunk before it waits for
+// anything, and it waits only for signals whose chunks were all handed out earlier than the chunk it would start next;
+// with at most kTeamWaves chunks of one signal per CU (host-checked) the oldest unresolved signal of a team can always
+// complete.  Mailbox slots (kTeamMailSlots per team, indexed by the signal's ordinal in the team's list) are recycled
+// safely because a CU does not START a chunk more than kTeamWindow signals ahead of its own oldest unresolved one
+// (2 kTeamWindow + 2 <= kTeamMailSlots; argument in DESIGN.md section 4.1b).  All blocks of the grid must be resident at
+// once (grid <= number of CUs, one block per CU by its 256-VGPR waves); every wait is bounded in wall-clock time and
+// reports through the plan's status word instead of hanging.
+#pragma once
+#include "fsst_mfma128.hpp"
+
+namespace hssfsst {
+
+constexpr int kTeamWaves = 8;                // waves per block: two per SIMD, up to 256 VGPRs each
+constexpr int kTeamGpc = 4;                  // groups per chunk = one 64-frame tile = one statistics block
+constexpr int kTeamMailSlots = 64;           // mailbox slots per team (signal ordinal mod this)
+constexpr int kTeamWindow = 31;              // a CU starts no chunk this many signals ahead of its oldest unresolved signal
+constexpr int kTeamMaxChunks = 64;           // chunks per signal the mailbox layout allows (signals up to 4096 frames)
+constexpr int kTeamPf = 2;                   // mailbox blocks per lane requested in one go (16 kTeamPf chunks = 2048 frames)
+constexpr int kTeamCtlFloats = 16 + 64 + 192;    // [0] work counter, [1] a wait gave up, [8..15] oldest unresolved signal per
+                                                 // wave, [16..79] column classes, [80..271] wide-store offsets
+static_assert(kStatBlock == kTeamGpc, "one published block sum per chunk: the chunk is the statistics block");
+static_assert(2 * kTeamWindow + 2 <= kTeamMailSlots, "mailbox recycling argument");
+
+struct Team128Params {
+    const float* x;       // [nsig][xstride]
+    float* out;           // [nsig][ncols][2K]
+    const float* atab;    // MFMA A-operand constants, then the wide-store offset table (as Core128Params)
+    const double* wtab;   // rounding-tie path tables
+    const double* twtab;
+    unsigned long long* mail;   // [teams][kTeamMailSlots][nchunks][8] tagged words {tag << 32 | half of a double}
+    unsigned* status;     // device status word (0 = ok)
+    float r2scale;
+    int n, klo, K, nsig, col0, ncols;
+    long long xstride;
+    int team;             // CUs per team (power of two, <= 32, <= nchunks)
+    int cpc;              // list positions per CU and signal: ceil(nchunks / team) rounded up to a power of two (<= kTeamWaves)
+    int cpc_shift;        // log2(cpc)
+    int nchunks;          // chunks per signal
+    unsigned seq;         // launch sequence number of the plan (upper half of the mailbox tags)
+    unsigned spin_ticks;  // bound of a wait in 100 MHz ticks
+    unsigned long long* probe;   // development (HSS_TEAM_PROBE): per-phase shader-clock totals over all waves
+};
+
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+
+template <int S1C>
+__global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team128Params p)
+{
+    constexpr int NT = 16, RQ = 8, NWIN = 128, KST = 2, FPW = 16 * kTeamGpc, WPB = kTeamWaves;
+    constexpr int ATAB = core128_atab_floats(RQ, NT);
+    constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
+    using avec = float __attribute__((ext_vector_type(KST)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = p.K, klo = p.klo, n = p.n;
+    const int LDF = plane_ldf(K);
+    const int OLD = own_ld(klo, K, RQ);
+    const int s0 = (S1C >= 0) ? 0 : own_s0(klo, RQ), s1 = (S1C >= 0) ? S1C : own_s1(klo, K, RQ);
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* atab = smem;
+    int* next_q = reinterpret_cast<int*>(smem + ATAB);
+    unsigned* dead = reinterpret_cast<unsigned*>(smem + ATAB) + 1;
+    int* pend = reinterpret_cast<int*>(smem + ATAB) + 8;                     // [kTeamWaves]
+    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64]
+    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // [3][64]
+    float* wbase = smem + ATAB + kTeamCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
+    float* xs = wbase;
+    f2* own_base = reinterpret_cast<f2*>(wbase + XS);
+    f2* disp_base = own_base + 16 * OLD;
+    int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
+    int* tq = flag + 4;
+
+    for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) {
+        const int ks = i % KST, l = (i / KST) & 63, pt = i / (KST * 64);
+        atab[i] = p.atab[(pt * KST + ks) * 64 + l];
+    }
+    const int ncols = p.ncols, cend = p.col0 + p.ncols;
+    for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+    if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
+    if (threadIdx.x < 8) next_q[threadIdx.x] = 0;
+    if (threadIdx.x >= 8 && threadIdx.x < 16) next_q[threadIdx.x] = 0x7fffffff;      // pend[]: nothing unresolved
+    if (wv == 0) {
+        unsigned cls = 0u;                               // bit 2i / 2i+1: the first / second pair of float4 i is imaginary
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned c = (4u * static_cast<unsigned>(lane + 64 * i)) % static_cast<unsigned>(2 * K);
+            cls |= (c >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i);
+            cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
+        }
+        cls_lds[lane] = cls;
+        const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            ppk_lds[i * 64 + lane] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
+    }
+    __syncthreads();
+
+    // ---- team geometry (wave-uniform).  Blocks are dealt to the XCDs round-robin (block b runs on XCD b % 8), so the
+    //      T blocks {b : b % 8 == x, (b / 8) / T == h} are T CUs of ONE XCD: their mailbox lives in that XCD's L2.
+    //      (Only performance depends on that placement: the mailbox protocol is agent-scope.)
+    const int T = p.team, cpc = p.cpc, NC = p.nchunks;
+    const int xcd = static_cast<int>(blockIdx.x) & 7, cu_slot = static_cast<int>(blockIdx.x) >> 3;
+    const int member = cu_slot & (T - 1);
+    const int team = xcd + 8 * (cu_slot / T);
+    const int nteams = static_cast<int>(gridDim.x) / T;
+    const int nk = (p.nsig > team) ? (p.nsig - team + nteams - 1) / nteams : 0;      // signals of this team
+    const int nwork = nk * cpc;
+    const int ngroups = (ncols + 15) >> 4;
+    const double total = static_cast<double>(K) * static_cast<double>(ncols);
+    gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * kTeamMailSlots * NC * 8;
+    const unsigned t_start = static_cast<unsigned>(wall_clock64());
+
+    const float* myA = atab + lane * KST;
+    f2 tiny = {1.0e-37f, 0.0f};
+    asm volatile("" : "+s"(tiny));
+
+    auto gave_up = [&](unsigned code) {
+        if (lane == 0) {
+            __hip_atomic_store((gu32*)(p.status), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto expired = [&]() -> bool {
+        return static_cast<unsigned>(wall_clock64()) - t_start > p.spin_ticks ||
+               __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+    };
+
+#ifdef HSS_TEAM_PROBE
+    unsigned long long pr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pr_last = __builtin_readcyclecounter();
+    const unsigned long long pr_begin = pr_last;
+#define PROBE(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); pr_t[k] += now_ - pr_last; pr_last = now_; } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
+    // Register sets.  One set = the lane's 12 float4s of a chunk (4 groups x 3), kept as three 16-float vectors indexed
+    // [4 group + component]: the group index is wave-uniform, so writing a group's float4 is four M0-indexed moves,
+    // not a ladder of 48 conditional copies.  `cur` is filled by the transform, `prev` waits for statistics.
+    using f16v = float __attribute__((ext_vector_type(16)));
+    bool have_prev = false;
+    int ko_prev = 0, grp0_prev = 0, ngrp_prev = 0;
+    long long b_prev = 0;
+    f16v prev[3], cur[3];
+
+    // ---- draw: the next chunk of this CU's list (-> it_valid, ko, c) and its samples on their way into registers.
+    //      The wave first registers a lower bound of the oldest signal it will hold unresolved -- `lower_hint`, or the
+    //      signal of the list position it is about to draw or pass: the window test of its siblings must see it before
+    //      the draw is visible (LDS executes a wave's operations in order; the fence only stops the compiler).
+    constexpr int SREG = (FPW + NWIN - 1 + 63) / 64;
+    float sreg[SREG];
+    bool d_valid = false;                                // the DRAWN chunk: samples requested, not yet in LDS
+    int ko_d = 0, c_d = 0;
+    bool it_valid = false;                               // the LANDED chunk: its tile is in xs, next to be transformed
+    int ko = 0, c = 0;
+    float R2 = 0.0f;                                     // error-bound scale of the tile in xs (see "Rounding ties")
+    auto draw = [&](int lower_hint) {
+        int qi = 0;
+        if (lane == 0) {
+            const int snap = __hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int lower = min(lower_hint, min(snap, nwork) >> p.cpc_shift);
+            __hip_atomic_store(pend + wv, lower, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        d_valid = false;
+        while (qi < nwork) {
+            ko_d = qi >> p.cpc_shift;
+            c_d = ((member + ko_d) & (T - 1)) + T * (qi & (cpc - 1));
+            if (c_d < NC) { d_valid = true; break; }
+            if (lane == 0) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            qi = __builtin_amdgcn_readfirstlane(qi);
+        }
+        if (d_valid) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const float* xsig = p.x + (static_cast<long long>(team) + static_cast<long long>(ko_d) * nteams) * p.xstride;
+            const int t0 = p.col0 + c_d * (16 * kTeamGpc);
+#pragma unroll
+            for (int k = 0; k < SREG; ++k) {
+                const int gi = t0 + lane_o + 64 * k - NWIN / 2;
+                sreg[k] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+            }
+        }
+    };
+    // ---- land: the drawn chunk's samples from registers into the (free) LDS tile, and the tile's error-bound scale
+    auto land = [&]() {
+        it_valid = d_valid; ko = ko_d; c = c_d;
+        d_valid = false;
+        if (!it_valid) return;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        float e2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SREG; ++k) {
+            if (lane_o + 64 * k < FPW + NWIN - 1) xs[lane_o + 64 * k] = sreg[k];
+            e2 = fmaf(sreg[k], sreg[k], e2);             // (a sample beyond the tile belongs to the next one: harmless in a bound)
+        }
+        R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+        wave_sync();
+    };
+    draw(0x7fffffff);
+    land();
+    if (it_valid) draw(ko);
+
+    // The wave works on three chunks at a time: HELD (transformed and published, features in `prev`, waiting for its
+    // signal's statistics), LANDED (tile in LDS, transformed next) and DRAWN (samples on their way into registers).
+    // One loop body, in this order -- a wave's memory operations retire in order and the compiler cannot count the ones
+    // issued under an exec mask, so the ONE wait for loaded data per iteration sits where everything else in flight is
+    // at least a group old:
+    //   1. transform the landed chunk; at the start of its LAST group ask the mailbox for the held chunk's signal
+    //      (published a whole chunk ago) and look at the answer right after the group: the one wait;
+    //   2. land the drawn chunk (its samples were requested a chunk ago), publish the transformed chunk's block sum,
+    //      draw the next chunk and request its samples;
+    //   3. statistics of the held chunk's signal (mailbox passes only if step 1's answer was incomplete);
+    //   4. z-score the held chunk's registers and stream them out: 12 stores that drain while step 1 runs again.
+    // A landed chunk kTeamWindow signals ahead of the held one is transformed one iteration later (steps 3, 4 first).
+    // With at most two chunks of a signal per CU (host-checked) a wave never holds three chunks of one signal, which is
+    // what rules out waiting for a block sum that only the waiting wave itself could publish.
+    for (;;) {
+        const bool xf = it_valid && !(have_prev && ko - ko_prev >= kTeamWindow);
+        long long b = 0;
+        int grp0 = 0, ngrp = 0, ko_cur = 0;
+        bool done = false;                               // the held chunk's signal: all block sums seen, summed in `acc`
+        double acc = 0.0;
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
+        const unsigned tag_prev = (p.seq << 16) | (static_cast<unsigned>(ko_prev) & 0xffffu);
+        const gu64* slot_prev = mail + static_cast<size_t>(ko_prev & (kTeamMailSlots - 1)) * NC * 8;
+        if (xf) {
+            PROBE(7);
+            // ---- window: do not start a chunk kTeamWindow signals ahead of the oldest unresolved signal of a sibling
+            for (;;) {
+                int fl = 0x7fffffff;
+                if (lane < kTeamWaves && lane != wv) fl = __hip_atomic_load(pend + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int off = 1; off < kTeamWaves; off <<= 1) fl = min(fl, __shfl_xor(fl, off));
+                if (ko - __builtin_amdgcn_readfirstlane(fl) < kTeamWindow) break;
+                if (expired()) { gave_up(4u); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            PROBE(0);
+            // ---- 1. transform chunk c of signal b: kTeamGpc groups of 16 frames out of the staged tile
+            b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
+            grp0 = c * kTeamGpc;
+            ngrp = min(kTeamGpc, ngroups - grp0);
+            ko_cur = ko;
+            const int c_cur = c;
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int g = lane_o >> 4, j = lane_o & 15;
+            f2* row_disp = disp_base + j * LDF;
+            const int t0 = p.col0 + grp0 * 16;
+            double bsum = 0.0;                                       // lane of row q: quantity q of this chunk's block sum
+            unsigned long long pf[2 * kTeamPf];
+#pragma unroll
+            for (int r = 0; r < 2 * kTeamPf; ++r) pf[r] = 0ull;
+            const bool pf_on = have_prev && NC <= 16 * kTeamPf;
+            for (int grp = 0; grp < ngrp; ++grp) {
+                if (pf_on && grp == ngrp - 1) {
+#pragma unroll
+                    for (int r = 0; r < kTeamPf; ++r) {
+                        const int blk = min((lane_o >> 2) + 16 * r, NC - 1);
+                        pf[2 * r] = __hip_atomic_load(slot_prev + blk * 8 + (lane_o & 3) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pf[2 * r + 1] = __hip_atomic_load(slot_prev + blk * 8 + (lane_o & 3) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const int tg = t0 + grp * 16;
+                unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + j + NT * g)));
+                asm volatile("" : "+v"(xaddr));
+                const lds_float* xb = (const lds_float*)static_cast<size_t>(xaddr);
+                int pair = g;
+                asm volatile("" : "+v"(pair));
+                const bool isg0 = (pair == 0);
+                const int rAi = pair, rBi = isg0 ? RQ / 2 : RQ - pair;
+                f2* ownA = own_base + j * OLD + rAi - RQ * s0;
+                f2* ownB = own_base + j * OLD + rBi - RQ * s0;
+
+                f2 za[NT], zb[NT];
+                static_for<NT / 4>([&](auto GG) {
+                    constexpr int g0 = decltype(GG)::value * 4;
+                    f4 acc4[4];
+                    avec a2[4];
+                    static_for<4>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        a2[i] = *reinterpret_cast<const avec*>(myA + (g0 + i) * 64 * KST);
+                        acc4[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][0], xb[g0 + i], f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<4>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        acc4[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i][1], xb[g0 + i + 4 * NT], acc4[i], 0, 0, 0);
+                    });
+                    static_for<4>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        za[bitrev_n<NT>(g0 + i)] = f2{acc4[i].x, acc4[i].y};
+                        zb[bitrev_n<NT>(g0 + i)] = f2{acc4[i].z, acc4[i].w};
+                    });
+                });
+                fft_n<NT>(za);
+                fft_n<NT>(zb);
+                static_for<NT / 2>([&](auto SS) {
+                    constexpr int s = decltype(SS)::value;
+                    const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
+                    const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
+                    const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+                    const bool st = (s >= s0) && (s <= s1);
+                    process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, tq, j, klo, K, rAi, rBi, R2);
+                });
+                if (s1 == NT / 2 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[NT / 2].x, 0.0f};
+                wave_sync();
+                int f_dirty = flag[0];
+                const int f_ties = tq[0] | tq[1];
+                if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {
+                    resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, p.wtab, p.twtab, lane_o);
+                    wave_sync();
+                    f_dirty = flag[0];
+                }
+                const bool wdirty = __builtin_amdgcn_readfirstlane(f_dirty) != 0;
+                const int nvalid = min(16, cend - tg);
+                const int koff = klo - RQ * s0;
+                f2* src = own_base + j * OLD + koff + g;
+                if (wdirty) {
+                    const f2* dsp = disp_base + j * LDF + g;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (g + 4 * u < K) src[4 * u] += dsp[4 * u];
+                    wave_sync();
+                }
+                // statistics partial of the group: the arithmetic of fsst_core128_kernel's FAST epilogue, then its
+                // float64 moments about zero added to the chunk's block sum exactly as signal_stats() adds a block's pieces
+                {
+                    const f2 piv = own_base[koff];
+                    f2 v[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) v[u] = src[4 * u];
+                    const int ufull = (nvalid == 16) ? (K >> 2) : 0;
+                    const bool jv = j < nvalid;
+                    f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const f2 d = v[u] - piv;
+                        if (u < ufull) {
+                            st_s += d; st_q = pk_fma(d, d, st_q);
+                        } else if (4 * u < K) {
+                            const bool ok = jv && (g + 4 * u < K);
+                            const f2 dm = {ok ? d.x : 0.0f, ok ? d.y : 0.0f};
+                            st_s += dm; st_q = pk_fma(dm, dm, st_q);
+                        }
+                    }
+                    const float w = piece_sums(st_s.x, st_q.x, st_s.y, st_q.y);      // row 0 / 1 / 2 / 3: S1re / S2re / S1im / S2im
+                    const float wo = __shfl_xor(w, 16);                              // the other sum of this row's block of columns
+                    const int q = lane_o >> 4;
+                    const float s1f = (q & 1) ? wo : w, s2f = (q & 1) ? w : wo;
+                    const float pf32 = (q & 2) ? piv.y : piv.x;
+                    const double cnt = static_cast<double>(nvalid) * static_cast<double>(K);
+                    bsum += piece_moment(q, static_cast<double>(s1f), static_cast<double>(s2f), static_cast<double>(pf32), cnt);
+                }
+                // the group's image [nvalid][2K] as lane-linear float4s, from the own plane into the register set
+                {
+                    const char* ob = reinterpret_cast<const char*>(own_base);
+                    const int e0 = 4 * grp;                          // wave-uniform element index: M0-indexed moves
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const unsigned pk = ppk_lds[i * 64 + lane_o];
+                        const int p0 = static_cast<int>(pk & 0xffffu), p1 = static_cast<int>(pk >> 16);
+                        cur[i][e0] = *reinterpret_cast<const float*>(ob + p0);
+                        cur[i][e0 + 1] = *reinterpret_cast<const float*>(ob + p0 + 8);
+                        cur[i][e0 + 2] = *reinterpret_cast<const float*>(ob + p1);
+                        cur[i][e0 + 3] = *reinterpret_cast<const float*>(ob + p1 + 8);
+                    }
+                }
+                wave_sync();
+                if (wdirty) {
+                    for (int i = lane_o; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+                    if (lane_o == 0) *flag = 0;
+                    wave_sync();
+                }
+            }
+            PROBE(1);
+            // ---- the answer of the early mailbox request (nothing else of this wave is in flight behind it).
+            //      Lane (blk % 16, q) adds up quantity q of blocks blk, blk + 16, ... in that order (stats_from_blocks).
+            if (pf_on) {
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < kTeamPf; ++r) {
+                    if ((lane_o >> 2) + 16 * r < NC) {
+                        ok = ok && static_cast<unsigned>(pf[2 * r] >> 32) == tag_prev && static_cast<unsigned>(pf[2 * r + 1] >> 32) == tag_prev;
+                        acc += __longlong_as_double(static_cast<long long>((pf[2 * r] << 32) | (pf[2 * r + 1] & 0xffffffffull)));
+                    }
+                }
+#if defined(HSS_TEAM_ABLATE) && HSS_TEAM_ABLATE >= 1    // development: cost of waiting for the team (results invalid)
+                ok = true;
+#endif
+                done = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+            }
+            PROBE(3);
+            // ---- 2. the drawn chunk's samples (requested a chunk ago) into the tile the transform is done with; then
+            //      publish the chunk's block sum: lanes 16 q and 16 q + 1 hold quantity q; word {tag, upper | lower half}
+            land();
+            {
+                const unsigned tag = (p.seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
+                gu64* slot = mail + (static_cast<size_t>(ko_cur & (kTeamMailSlots - 1)) * NC + c_cur) * 8;
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(bsum));
+                if ((lane_o & 15) < 2) {
+                    const int q = lane_o >> 4, half = lane_o & 1;
+                    const unsigned payload = half ? static_cast<unsigned>(bits) : static_cast<unsigned>(bits >> 32);
+                    __hip_atomic_store(slot + q * 2 + half, (static_cast<unsigned long long>(tag) << 32) | payload,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            //      next chunk: draw it and request its samples (oldest unresolved signal of this wave from now on: the
+            //      held chunk's, else the one just transformed)
+            if (it_valid) draw(have_prev ? ko_prev : ko_cur);
+            PROBE(2);
+        }
+        // ---- 3. statistics of the held chunk's signal
+        f2 ms[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ms[i][0] = f2{0.0f, 0.0f}; ms[i][1] = f2{0.0f, 0.0f}; }
+        if (have_prev) {
+            PROBE(7);
+            // mailbox passes with ALL loads of a pass in flight at once: under load a mailbox read is a 2-3 us trip through
+            // this CU's own memory queue (MI355X_MICROARCH.md, handoff-1to1)
+            while (!done) {
+                bool ok = true;
+                acc = 0.0;
+                for (int blk0 = lane_r >> 2; blk0 < NC; blk0 += 16 * kTeamPf) {
+                    unsigned long long w[2 * kTeamPf];
+#pragma unroll
+                    for (int r = 0; r < kTeamPf; ++r) {
+                        const int blk = min(blk0 + 16 * r, NC - 1);
+                        w[2 * r] = __hip_atomic_load(slot_prev + blk * 8 + (lane_r & 3) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[2 * r + 1] = __hip_atomic_load(slot_prev + blk * 8 + (lane_r & 3) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int r = 0; r < kTeamPf; ++r) {
+                        if (blk0 + 16 * r < NC) {
+                            ok = ok && static_cast<unsigned>(w[2 * r] >> 32) == tag_prev && static_cast<unsigned>(w[2 * r + 1] >> 32) == tag_prev;
+                            acc += __longlong_as_double(static_cast<long long>((w[2 * r] << 32) | (w[2 * r + 1] & 0xffffffffull)));
+                        }
+                    }
+                }
+#if defined(HSS_TEAM_ABLATE) && HSS_TEAM_ABLATE >= 1
+                break;
+#endif
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (expired()) { gave_up(3u); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            PROBE(3);
+#if defined(HSS_TEAM_ABLATE) && HSS_TEAM_ABLATE >= 2    // development: cost of the float64 statistics per chunk
+            const float4 st = make_float4(static_cast<float>(acc), 1.0f, 0.0f, 2.0f);
+#else
+            const float4 st = stats_finish(acc, total, lane_r);
+#endif
+            // {mean, 1/std} of each of the lane's six pairs (3 float4 x 2) as ONE register pair: the packed subtract /
+            // multiply of step 5 broadcast its low / high half (VOP3P op_sel)
+            const unsigned cls = cls_lds[lane_r];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
+                ms[i][0] = f2{im0 ? st.z : st.x, im0 ? st.w : st.y};
+                ms[i][1] = f2{im1 ? st.z : st.x, im1 ? st.w : st.y};
+            }
+            PROBE(4);
+        }
+        // ---- 4. z-score of the held chunk: (v - mean) * (1 / std), two roundings, exactly as fsst_normalize_kernel
+        if (have_prev) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(ms[i][0]), "+v"(ms[i][1]));
+            auto zs = [](f2 v, f2 m) -> f2 {
+                f2 d, e;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(m));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(e) : "v"(d), "v"(m));
+                return e;
+            };
+            const int C = 2 * K;
+            float4* d4 = reinterpret_cast<float4*>(p.out + (b_prev * static_cast<long long>(ncols) + grp0_prev * 16) * C) + lane_r;
+            const int per = 8 * K;                       // float4 per full group
+#if !defined(HSS_TEAM_ABLATE) || HSS_TEAM_ABLATE < 3
+#pragma unroll
+            for (int g = 0; g < kTeamGpc; ++g) {
+                const int lim = (g < ngrp_prev) ? min(16, ncols - (grp0_prev + g) * 16) * (K >> 1) : 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (lane_r + 64 * i < lim) {
+                        const f2 lo = zs(f2{prev[i][4 * g], prev[i][4 * g + 1]}, ms[i][0]);
+                        const f2 hi = zs(f2{prev[i][4 * g + 2], prev[i][4 * g + 3]}, ms[i][1]);
+#if defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 1        // development: plain stores
+                        *reinterpret_cast<f4*>(d4 + g * per + 64 * i) = f4{lo.x, lo.y, hi.x, hi.y};
+#elif defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 2      // development: the arithmetic without the stores
+                        { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
+#elif defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 3      // development: every wave stores into one small region (L2-resident)
+                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(reinterpret_cast<float4*>(p.out) + (blockIdx.x * 8 + wv) * 1024 + lane_r + 64 * (3 * g + i)));
+#else
+                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + g * per + 64 * i));
+#endif
+                    }
+                }
+            }
+#else
+            if (lane_r == 0 && prev[0][0] == 123.456f) p.out[0] = ms[0][0].x + ms[1][1].y;
+#endif
+            have_prev = false;
+            PROBE(5);
+        }
+        if (xf) {
+            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            have_prev = true; ko_prev = ko_cur; grp0_prev = grp0; ngrp_prev = ngrp; b_prev = b;
+        } else if (!it_valid) {
+            break;
+        }
+    }
+#ifdef HSS_TEAM_PROBE
+    // [0] window wait, [1] transform, [2] publish + draw, [3] poll, [4] stats_finish, [5] z-score + stores, [7] rest, [6] lifetime
+    if (lane == 0) {
+        pr_t[6] = __builtin_readcyclecounter() - pr_begin;
+        for (int k = 0; k < 8; ++k) atomicAdd(p.probe + k, pr_t[k]);
+        atomicAdd(p.probe + 8, 1ull);
+    }
+#endif
+    if (lane == 0) __hip_atomic_store(pend + wv, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+}  // namespace hssfsst

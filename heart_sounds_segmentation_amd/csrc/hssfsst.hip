@@ -17,6 +17,7 @@
 
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
+#include "fsst_team128.hpp"
 #include "fsst_dft.hpp"
 #include "fsst_gather.hpp"
 #include "fourier_resample.hpp"
@@ -155,8 +156,13 @@ struct hssfsst_plan {
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
     int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
     float* d_partials = nullptr;  size_t partials_cap = 0;   // floats (kPartFloats per statistics piece)
-    unsigned* d_status = nullptr;                            // fused z-score: device status word (0 = ok)
-    int last_fused = 0;                                      // the last exec ran the fused z-score kernel
+    unsigned* d_status = nullptr;                            // fused z-score: status word (0 = ok) as the device sees it ...
+    volatile unsigned* h_status = nullptr;                   // ... and the same word in pinned host memory: read without a sync
+    unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][chunks][8] (8-byte words)
+    unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
+    int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
+    int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
+    int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
@@ -217,8 +223,11 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
 template <int NT, int RQ, bool FAST, int WPB, int S1C = -1>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
-    const size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
+    size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
                         hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ, NT)) * sizeof(float);
+#ifdef HSS_LDS_PAD                                       // development: one block per CU whatever its size
+    if (lds < 100 * 1024) lds = 100 * 1024;
+#endif
     auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, FAST, WPB, S1C>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
@@ -247,6 +256,8 @@ int grow(void** ptr, size_t* cap, size_t need, size_t elem)
     return 0;
 }
 
+int ensure_status(hssfsst_plan* pl);
+
 // Fused z-score launch (nwin = 128, STACK, wide-store epilogue; fsst_mfma128.hpp "Fused z-score"): one persistent block
 // per CU, every CU owns whole signals.  Returns 1 when it launched, 0 when this exec should take the two-kernel path
 // (signal too long for the LDS partials, or a batch that would leave CUs idle for a whole signal), < 0 on error.
@@ -273,13 +284,97 @@ int launch_fused128(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, 
     const int64_t grid = pl->fused_slots;
     const int64_t rounds = (batch + grid - 1) / grid;
     if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
-    if (!pl->d_status) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_status), sizeof(unsigned)));
-        HIP_TRY(hipMemset(pl->d_status, 0, sizeof(unsigned)));
-    }
+    if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
+    return 1;
+}
+
+// The status word of the in-kernel waits lives in pinned, device-mapped host memory: a kernel that gave up writes it
+// with a system-scope store, and the host looks at it without synchronising (at the start of the next exec, in
+// hssfsst_plan_check after a synchronisation, at plan destruction).
+int ensure_status(hssfsst_plan* pl)
+{
+    if (pl->d_status) return 0;
+    void* h = nullptr;
+    HIP_TRY(hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
+    *static_cast<volatile unsigned*>(h) = 0u;
+    void* d = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+    pl->h_status = static_cast<volatile unsigned*>(h);
+    pl->d_status = static_cast<unsigned*>(d);
+    return 0;
+}
+
+// Team kernel launch (fsst_team128.hpp): nwin = 128, STACK, wide-store epilogue.  Returns 1 when it launched, 0 when
+// this exec should take another path, < 0 on error.
+template <int S1C>
+int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    using namespace hssfsst;
+    const int NC = (ngroups + kTeamGpc - 1) / kTeamGpc;
+    if (NC < 1 || NC > kTeamMaxChunks) return 0;
+    const size_t lds = (core128_atab_floats(8, 16) + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
+                        wave_lds_floats(16 * kTeamGpc, pl->klo, pl->K, 8, 16)) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    auto kern = fsst_team128_kernel<S1C>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->team_cus == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * kTeamWaves, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->team_cus = (per_cu >= 1 && cus >= 8) ? cus : -1;
+    }
+    if (pl->team_cus < 8) return 0;
+    // team size: the largest power of two <= min(32, chunks per signal, CUs per XCD) -- at most two chunks of a signal per CU
+    static const int team_env = std::getenv("HSSFSST_TEAM") ? std::atoi(std::getenv("HSSFSST_TEAM")) : 0;
+    int T = 1;
+    while (2 * T <= 32 && 2 * T <= NC && 8 * 2 * T <= pl->team_cus) T *= 2;
+    if (team_env > 0) { T = 1; while (2 * T <= team_env && 2 * T <= NC && 8 * 2 * T <= pl->team_cus) T *= 2; }
+    int cpc = 1, cpc_shift = 0;                          // list positions per CU and signal (power of two; surplus ones are skipped)
+    while (cpc * T < NC) { cpc *= 2; ++cpc_shift; }
+    if (cpc > 2) return 0;                               // the kernel's progress argument: a wave never holds three chunks of a signal
+    const int grid = (pl->team_cus / (8 * T)) * 8 * T;
+    const int nteams = grid / T;
+    if ((batch + nteams - 1) / nteams > 65535) return 0;
+    int rc;
+    if ((rc = ensure_status(pl)) != 0) return rc;
+    const size_t words = static_cast<size_t>(nteams) * kTeamMailSlots * NC * 8;
+    if (words > pl->mail_cap) {
+        if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
+        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
+        pl->team_seq = 0;
+    }
+    if (++pl->team_seq > 0xffffu) {                      // tags would repeat: start over from clean mailboxes
+        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
+        pl->team_seq = 1;
+    }
+    Team128Params tp{};
+    tp.x = cp.x; tp.out = cp.out; tp.atab = cp.atab; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
+    tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale = cp.r2scale;
+    tp.n = cp.n; tp.klo = cp.klo; tp.K = cp.K; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
+    tp.team = T; tp.cpc = cpc; tp.cpc_shift = cpc_shift; tp.nchunks = NC; tp.seq = pl->team_seq;
+    tp.spin_ticks = 200u * 1000u * 1000u;                // 2 s of the 100 MHz counter
+#ifdef HSS_TEAM_PROBE
+    static unsigned long long* d_probe = nullptr;
+    static int probe_runs = 0;
+    if (!d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_probe), 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_probe, 0, 16 * sizeof(unsigned long long), st));
+    tp.probe = d_probe;
+#endif
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * kTeamWaves), lds, st, tp);
+    HIP_TRY(hipGetLastError());
+#ifdef HSS_TEAM_PROBE
+    if (++probe_runs % 40 == 0) {
+        unsigned long long h[16];
+        HIP_TRY(hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost));
+        const double w = static_cast<double>(h[8] ? h[8] : 1);
+        fprintf(stderr, "[team probe] waves %llu, cycles per wave: window %.0f transform %.0f publish+draw %.0f poll %.0f stats %.0f zscore+stores %.0f rest %.0f | lifetime %.0f | resolves %llu prefetched %llu ready %llu\n",
+                h[8], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[7] / w, h[6] / w, h[9], h[10], h[11]);
+    }
+#endif
     return 1;
 }
 
@@ -307,16 +402,31 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     *did_fuse = false;
     if (try_fused && fast && nt == 16 && rq == 8 && pl->mode == HSSFSST_MODE_STACK) {
         const int ngroups = (ncols + 15) / 16;
-        const int rc = canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
+        // two single-launch z-score kernels: full batches of ~2000-sample signals take round 2's one-CU-per-signal kernel
+        // (16 waves per CU, the tile makes one HBM round trip inside the launch: 0.245 ms per 1024 windows); every other
+        // shape -- small or ragged batches, short signals -- the team kernel (8 waves per CU, features written once from
+        // registers: 0.258 ms per 1024 windows, but 1.2-1.9x faster than two launches where the former does not apply)
+        static const bool no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;         // A/B and tests
+        static const bool team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr;     // A/B and tests
+        int rc = 0;
+        if (!team_only) rc = canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
+        if (rc == 0 && !no_team) {
+            rc = canon ? launch_team128<3>(pl, cp, batch, ngroups, st) : launch_team128<-1>(pl, cp, batch, ngroups, st);
+            if (rc == 1) { *did_fuse = true; pl->last_zpath = 2; return 0; }
+        }
         if (rc < 0) return rc;
-        if (rc == 1) { *did_fuse = true; return 0; }
+        if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
     }
     if (nt == 16 && rq == 8) {
+#ifdef HSS_WPB_CANON
+        if (fast && canon) return launch_core128_wpb<16, 8, true, HSS_WPB_CANON, 3>(pl, cp, nchunks, st);
+#endif
         if (fast && canon) return launch_core128_wpb<16, 8, true, 16, 3>(pl, cp, nchunks, st);
         if (fast) return launch_core128_wpb<16, 8, true, 16>(pl, cp, nchunks, st);   // K <= 24: 16 regions always fit
         if (fixed + 16 * per_wave <= room) return launch_core128_wpb<16, 8, false, 16>(pl, cp, nchunks, st);
         if (fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 8, false, 8>(pl, cp, nchunks, st);
         if (fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 8, false, 4>(pl, cp, nchunks, st);
+#ifndef HSS_DEV_ONLY128
     } else if (nt == 16 && rq == 16) {                                               // nwin = 256
         // (8 waves per block at most: two per SIMD, up to 256 VGPRs, no scratch)
         if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, true, 8>(pl, cp, nchunks, st);
@@ -333,6 +443,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (!fast && fixed + 3 * per_wave <= room) return launch_core128_wpb<32, 16, false, 3>(pl, cp, nchunks, st);
         if (!fast && fixed + 2 * per_wave <= room) return launch_core128_wpb<32, 16, false, 2>(pl, cp, nchunks, st);
         if (fast && fixed + 2 * per_wave <= room) return launch_core128_wpb<32, 16, true, 2>(pl, cp, nchunks, st);
+#endif
     }
     return fail(HSSFSST_EUNSUPPORTED, "LDS request %zu B per wave exceeds the 160 KiB budget", per_wave);
 }
@@ -547,7 +658,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_dtab) (void)hipFree(p->d_dtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_partials) (void)hipFree(p->d_partials);
-    if (p->d_status) (void)hipFree(p->d_status);
+    if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
+    if (p->d_mail) (void)hipFree(p->d_mail);
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
@@ -575,17 +687,17 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
 }
 
 
-int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? 1 : 0; }
+int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? p->last_zpath : 0; }
 
 int hssfsst_plan_check(hssfsst_plan* p)
 {
     if (!p) return fail(HSSFSST_EINVAL, "plan_check: plan is NULL");
     if (!p->d_status) return 0;
     DEVICE_SCOPE(p->device);
-    unsigned code = 0;
-    HIP_TRY(hipMemcpy(&code, p->d_status, sizeof(code), hipMemcpyDeviceToHost));   // waits for the device
+    HIP_TRY(hipDeviceSynchronize());                     // every exec of this plan has finished
+    const unsigned code = *p->h_status;
     if (code != 0) {
-        (void)hipMemset(p->d_status, 0, sizeof(code));
+        *p->h_status = 0u;
         return fail(HSSFSST_EHIP, "fused z-score: a wait inside the kernel gave up (code %u); results of that exec are invalid", code);
     }
     return 0;
@@ -657,6 +769,14 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     if (batch == 0 || p->K == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEVICE_SCOPE(p->device);
+    // a wait inside an EARLIER exec's kernel gave up (pinned status word, no synchronisation): that exec's features are
+    // invalid and the caller of a device-output exec has not been told yet -- refuse until the plan is checked
+    if (p->h_status && *p->h_status != 0u) {
+        const unsigned code = *p->h_status;
+        *p->h_status = 0u;
+        return fail(HSSFSST_EHIP, "exec: a wait inside a previous exec's z-score kernel gave up (code %u); the results of that "
+                    "exec are invalid", code);
+    }
     const int ofps = out_floats_per_sample(p);
     const bool use128 = (p->d_atab != nullptr);
     // statistics partials per signal: one per 16-frame group (MFMA kernel) / per 64-frame tile (generic kernel)
@@ -794,9 +914,11 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;
+#ifndef HSS_DEV_ONLY128
             case 4: rc = launch_core<4>(p, cp, cblocks, st); break;
             case 8: rc = launch_core<8>(p, cp, cblocks, st); break;
             case 16: rc = launch_core<16>(p, cp, cblocks, st); break;
+#endif
             default: rc = fail(HSSFSST_EUNSUPPORTED, "exec: unsupported radix %d", p->R);
         }
         if (rc != 0) return rc;

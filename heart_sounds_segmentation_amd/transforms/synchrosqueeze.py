@@ -260,13 +260,15 @@ class FSST:
         _lib.check(rc, "hssfsst_exec_list")
         return out
 
-    def check(self, device_index: Optional[int] = None) -> bool:
-        """Extension: waits for the device and raises ``RuntimeError`` if a kernel reported a failed internal wait;
-        returns True when the plan's last ``stack`` call ran the fused (single-pass) kernel."""
+    def check(self, device_index: Optional[int] = None) -> int:
+        """Extension: waits for the device and raises ``RuntimeError`` if a kernel reported a failed internal wait
+        (the library also reports it at the start of the plan's next call, without being asked).  Returns the path of
+        the plan's last ``stack`` call: 0 = two launches, 1 = the one-CU-per-signal z-score kernel (full batches),
+        2 = the team kernel (features normalised in registers, written once); truthy = a single launch."""
         dev = self._device_index() if device_index is None else device_index
         plan = self._plan(dev)
         _lib.check(_lib.lib().hssfsst_plan_check(plan.handle), "hssfsst_plan_check")
-        return bool(_lib.lib().hssfsst_plan_last_exec_fused(plan.handle))
+        return int(_lib.lib().hssfsst_plan_last_exec_fused(plan.handle))
 
     def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
         """Extension (bench): record HIP events around the kernels of every following call."""

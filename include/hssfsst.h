@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 202
+#define HSSFSST_VERSION 203
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -97,14 +97,19 @@ int hssfsst_exec_frames(hssfsst_plan* plan, const float* x, int64_t batch, int n
 int hssfsst_exec_list(hssfsst_plan* plan, const float* x, int64_t x_len, const int64_t* starts, int starts_on_device,
                       int64_t batch, int n, int x_on_device, float* out, int out_on_device, void* stream);
 
-/* Device-side health of the plan's asynchronous work: waits for the device, then returns HSSFSST_EHIP if a bounded
- * wait inside a kernel gave up since the last check (never expected: it would mean the GPU did not keep the kernel's
- * blocks co-resident).  Host-output execs call it themselves; callers of device-output execs may call it after
- * synchronising. */
+/* Device-side health of the plan's asynchronous work.  The single-launch z-score kernels contain waits on other
+ * waves (of the same CU: the one-CU-per-signal kernel; of other CUs of a team: the team kernel, which needs all its
+ * blocks resident at once -- the library sizes its grid to the CUs of the device).  Every such wait is bounded (2 s) and
+ * a give-up is recorded in a status word in pinned host memory instead of hanging the GPU.  The library looks at that
+ * word without synchronising at the start of EVERY exec of the plan and returns HSSFSST_EHIP if an earlier exec's wait
+ * gave up (that exec's features are invalid), so a caller of device-output execs learns of it at the next call at the
+ * latest; host-output execs check before they return; this function waits for the device and checks now. */
 int hssfsst_plan_check(hssfsst_plan* plan);
 
-/* 1 when the plan's last STACK exec ran the fused core + z-score kernel (one pass over HBM), 0 when it took the
- * two-kernel path (short batches, long signals, other window lengths).  Both give bit-identical results. */
+/* Which path the plan's last STACK exec took: 0 = two launches (transform, then statistics + z-score sweep: long
+ * signals, other window lengths, odd or wide bands), 1 = the one-CU-per-signal kernel (full batches of 961..2048-sample
+ * signals), 2 = the team kernel (every other batch of signals up to 4096 samples: features stay in registers until
+ * the signal's statistics arrive from the team).  All three give bit-identical results. */
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* plan);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every

@@ -626,29 +626,80 @@ def test_bench_contract_json():
     assert "allgather_ms" in d["allgather"]
 
 
-@pytest.mark.parametrize("n,batch", [(2000, 1024), (2000, 517), (1999, 256), (1000, 300), (250, 512), (961, 512), (2048, 256), (33, 1024)])
+def _expected_zscore_path(n, batch):
+    """hssfsst_plan_last_exec_fused for the canonical configuration on a 256-CU device (hssfsst.hip launch_core128)."""
+    rounds = -(-batch // 256)
+    if 961 <= n <= 2048 and batch >= 256 and rounds * 256 * 100 <= batch * 112:
+        return 1                                          # one CU per signal, tile round-trips through HBM inside the launch
+    if -(-(-(-n // 16)) // 4) <= 64:
+        return 2                                          # team kernel: chunks of 4 groups, at most 64 per signal
+    return 0
+
+
+_ZS_CHILD = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
+             "from heart_sounds_segmentation_amd import FSST, synth; "
+             "X = synth.noise_windows(%d, %d, seed=%d); "
+             "tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True); "
+             "y = tf.batch(torch.from_numpy(X).cuda()); assert tf.check() == %d, tf.check(); np.save(%r, y.cpu().numpy())")
+
+
+@pytest.mark.parametrize("n,batch", [(2000, 1024), (2000, 517), (1999, 256), (1000, 300), (250, 512), (961, 512), (2048, 256), (33, 1024),
+                                     (2000, 50), (2000, 1), (2000, 1100), (4096, 5), (4100, 3), (64, 3), (130, 700)])
 def test_fused_zscore_bit_identical_to_two_kernel_path(n, batch):
-    """The fused core + z-score kernel (one persistent block per CU, statistics resolved in LDS) against the
-    two-kernel path (HSSFSST_NO_FUSED=1 in a child process): same bits, for full and ragged last rounds, a partial
-    last group, the longest signal the fused kernel takes, and sizes where the library must fall back by itself."""
+    """The two single-launch z-score kernels -- one CU per signal with the statistics resolved in LDS (full batches),
+    teams of CUs with the features held in registers and float64 block sums exchanged through mailboxes (everything
+    else) -- against the two-launch path (HSSFSST_NO_FUSED=1 in a child process): same bits, for full and ragged rounds,
+    a partial last group, a partial last chunk, one signal, the longest signals either kernel takes, and sizes where the
+    library must fall back by itself."""
     import subprocess, sys, tempfile
     X = synth.noise_windows(batch, n, seed=n + batch)
     tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
     got = tf.batch(torch.from_numpy(X).cuda())
-    fused = tf.check()                                    # raises if a wait inside the kernel gave up
-    rounds = -(-batch // 256)
-    assert fused == (961 <= n <= 2048 and batch >= 256 and rounds * 256 * 100 <= batch * 112) or torch.cuda.get_device_properties(0).multi_processor_count != 256
+    path = tf.check()                                     # raises if a wait inside the kernel gave up
+    assert path == _expected_zscore_path(n, batch) or torch.cuda.get_device_properties(0).multi_processor_count != 256
     got = got.cpu().numpy()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
-        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
-                "from heart_sounds_segmentation_amd import FSST, synth; "
-                "X = synth.noise_windows(%d, %d, seed=%d); "
-                "tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True); "
-                "y = tf.batch(torch.from_numpy(X).cuda()); assert not tf.check(); np.save(%r, y.cpu().numpy())"
-                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), batch, n, n + batch, os.path.join(td, "ref.npy")))
+        code = _ZS_CHILD % (root, batch, n, n + batch, 0, os.path.join(td, "ref.npy"))
         subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HSSFSST_NO_FUSED="1"), timeout=600)
         ref = np.load(os.path.join(td, "ref.npy"))
     assert np.array_equal(got, ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,batch", [(2000, 1024), (1999, 256), (2048, 517)])
+def test_team_kernel_on_full_batches(n, batch):
+    """Full batches normally take the one-CU-per-signal kernel; HSSFSST_TEAM_ONLY=1 (child process) sends them to the team
+    kernel: 128 signals per team and CU, the mailbox slots recycled twice, the window logic under load -- same bits."""
+    import subprocess, sys, tempfile
+    X = synth.noise_windows(batch, n, seed=n + batch)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    got = tf.batch(torch.from_numpy(X).cuda())
+    tf.check()
+    got = got.cpu().numpy()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        code = _ZS_CHILD % (root, batch, n, n + batch, 2, os.path.join(td, "ref.npy"))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HSSFSST_TEAM_ONLY="1"), timeout=600)
+        ref = np.load(os.path.join(td, "ref.npy"))
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
+def test_team_kernel_repeated_launches_and_shapes():
+    """One plan, many launches of the team kernel with changing (batch, n): the mailbox tags carry the launch number, so
+    words left by earlier launches (other layouts included) are never taken for this launch's; results equal the
+    two-launch path of a second plan (un-normalised features z-scored in float64 by torch)."""
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    for it, (batch, n) in enumerate([(7, 2000), (40, 1000), (7, 2000), (3, 320), (90, 2000), (7, 2000)] * 3):
+        X = torch.from_numpy(synth.pcg_windows(batch, n, seed=it)).cuda()
+        got = tf.batch(X)
+        assert tf.check() == 2 or torch.cuda.get_device_properties(0).multi_processor_count != 256
+        raw = tf.unnormalized(X).double()
+        for h in (slice(0, 22), slice(22, 44)):
+            blk = raw[..., h]
+            m = blk.mean(dim=(1, 2), keepdim=True)
+            sd = blk.flatten(1).std(dim=1, unbiased=True)[:, None, None]
+            want = ((blk - m) / sd).float()
+            assert (got[..., h] - want).abs().max() <= 2e-5 * want.abs().max(), (it, batch, n)
 
 
 @pytest.mark.parametrize("band", [None, (0, 20), (0, 7), BAND])
@@ -788,7 +839,7 @@ def test_stack_over_a_column_range(batch):
     tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
     cols = (160, 1696)                                     # 106 groups: inside the fused kernel's range
     got = tf._run(X, cols=cols)
-    assert tf.check() == (batch >= 256) or torch.cuda.get_device_properties(0).multi_processor_count != 256
+    assert tf.check() == (1 if batch >= 256 else 2) or torch.cuda.get_device_properties(0).multi_processor_count != 256
     raw = tf.unnormalized(X, cols=cols).double()
     assert got.shape == raw.shape == (batch, 1696, 44)
     for h in (slice(0, 22), slice(22, 44)):
