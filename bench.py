@@ -32,22 +32,23 @@ VALU_FLOP_PER_LANE = 2.0                         # estimate: the VALU mix is ~ha
 
 
 def csrc_digest():
-    """SHA-256 of the device code of the benchmarked kernels (csrc/fsst_mfma128.hpp + csrc/fsst_kernels.hpp): PMC
-    figures committed under profiles/ are only quoted for the kernels they were measured on."""
+    """SHA-256 of every source under csrc/ and of the C header: PMC figures committed under profiles/ are only quoted
+    for the library they were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "heart_sounds_segmentation_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f in ("fsst_mfma128.hpp", "fsst_kernels.hpp"):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    files = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".hpp", ".h"))]
+    files.append(os.path.join(ROOT, "include", "hssfsst.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()
 
 
 def pmc_profile(kernel_substr):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
-    (profiles/r02_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
-    MI355X guide prescribes).  None when the file is absent or was measured on other kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    (profiles/r03_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
+    MI355X guide prescribes).  None when the file is absent or was measured on other sources."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -59,6 +60,47 @@ def pmc_profile(kernel_substr):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def live_traffic(kernel_substr, batch, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two short child runs of this very script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no tracing, as MI355X_MICROARCH.md prescribes:
+    counter values are KiB per dispatch, FETCH_SIZE reports half of a wide streaming read on gfx950 and is doubled).
+    None when rocprofv3 is unavailable or a pass fails -- never a stale constant."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="hss_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                   "--steps", "3", "--warmup", "1", "--settle-steps", "0", "--batch", str(batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(td, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            rows = list(db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? "
+                                   "group by kernel_name", (ctr,)))
+            hit = [v for name, v, cnt in rows if kernel_substr in name]
+            if not hit:
+                return None
+            vals[ctr] = float(hit[0])
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return {"hbm_bytes_per_launch": int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)),
+            "FETCH_SIZE_KiB": round(vals["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(vals["WRITE_SIZE"], 1),
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script (3 steps each) inside this run; "
+                   "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch"}
 
 
 def cpu_baseline(X, w, budget_s=12.0):
@@ -110,7 +152,7 @@ def self_launch(ngpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def bench_c5(args):
+def bench_c5(steps, warmup):
     """BASELINE config 5: 64 channels x 4 kHz, 128 new samples per channel and step, rolling FSST (nwin 512 = the
     same 128 ms window and 7.8125 Hz grid as the canonical configuration), running-moments z-score.  Reports
     device-resident steps/s and the HOST-VISIBLE latency of a step: last sample of a chunk in a host buffer ->
@@ -126,15 +168,15 @@ def bench_c5(args):
     ch, fs, chunk, nwin = 64, 4000, 128, 512
     w = get_window(("kaiser", 0.5), nwin, fftbins=False)
     st = StreamingFSST(ch, fs, w, truncate_freq=(25, 200), chunk=chunk, device=dev)
-    steps, warm = args.steps, max(args.warmup, 20)
+    steps, warm = steps, max(warmup, 20)
     xh = synth.pcg_windows(ch, chunk * 64, fs=fs, seed=2)
     xd = torch.from_numpy(xh).to(dev)
     for i in range(warm):
-        st.step(xd[:, (i % 64) * chunk:(i % 64 + 1) * chunk])
+        st.step(xd[:, (i % 64) * chunk:(i % 64 + 1) * chunk], copy=False)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        st.step(xd[:, (i % 64) * chunk:(i % 64 + 1) * chunk])
+        st.step(xd[:, (i % 64) * chunk:(i % 64 + 1) * chunk], copy=False)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     lat = []
@@ -159,7 +201,117 @@ def bench_c5(args):
             "roofline": {"bound": "hbm", "achieved": round((ch * chunk * 4 + ch * chunk * 44 * 4) / dt / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round((ch * chunk * 4 + ch * chunk * 44 * 4) / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": "launch-latency bound: 1.47 MB per step"}}
-    print(json.dumps(line), flush=True)
+    return line
+
+
+def bench_c3(dev, rank, world, use_dist, steps, warmup, nrec=792, T=35500, host_fed=True):
+    """BASELINE config 3: the corpus preprocessing of /root/reference/hss/datasets/heart_sounds.py:155-169 -- every
+    recording framed (stride 1000, length 2000: 33 frames per 35 500-sample recording) and every frame transformed --
+    on a 792-recording stand-in (26 136 windows; the Springer corpus itself needs a download), RECORDINGS split in
+    contiguous blocks over the ranks (framing stays local), frame-list launches of <= 4096 windows
+    (hssfsst_exec_list), then ONE ragged all-gather of the feature blocks on the process group's device.  Timed with
+    the recordings resident in HBM; strong scaling (the corpus is fixed).  `host_fed`: corpus.build_features from host
+    recordings (pinned double-buffered uploads), device-kept and host-returned, on a quarter of the corpus."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from heart_sounds_segmentation_amd import FSST, corpus, dist as hdist, synth
+    from heart_sounds_segmentation_amd.framing import frame_starts
+    n, stride = 2000, 1000
+    w = synth.kaiser_window(128, 0.5)
+    tf = FSST(1000, w, truncate_freq=(25, 200), stack=True, device=dev)
+    lo, hi = hdist.shard_bounds(nrec, world, rank)
+    # stand-in recordings: 8 distinct synthetic recordings, rolled by a recording-specific offset (generating 792
+    # independent ones costs a minute of numpy; the transform's cost does not depend on the content)
+    base = [synth.recording(T, seed=synth.SEED + 10 + i) for i in range(8)]
+    recs = [np.roll(base[i % 8], 97 * i) for i in range(lo, hi)]
+    st1 = frame_starts(T, stride, n)[0]
+    per = int(st1.shape[0])
+    mine = per * len(recs)
+    groups, g = [], 0
+    gsz = max(1, 4096 // per)                                  # recordings per launch
+    xd = torch.from_numpy(np.concatenate(recs) if recs else np.zeros(0, np.float32)).to(dev)
+    while g < len(recs):
+        k = min(gsz, len(recs) - g)
+        starts = torch.from_numpy(np.concatenate([st1 + (g + j) * T for j in range(k)])).to(dev)
+        groups.append((g * per, k * per, starts))
+        g += k
+    arena = torch.empty((mine, n, 44), dtype=torch.float32, device=dev)
+
+    def step():
+        for row, cnt, starts in groups:
+            tf.frames(xd, starts, n, out=arena[row:row + cnt])
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(warmup, 1)):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    el = time.perf_counter() - t0
+    tf.check()
+    gather = None
+    total = per * nrec
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        try:
+            items = corpus.FrameItems(arena, None)
+            full = corpus.gather_features(items)               # warm-up
+            ok = tuple(full.shape) == (total, n, 44) and full.is_cuda
+            sync_all()
+            g0 = time.perf_counter()
+            full = corpus.gather_features(items)
+            sync_all()
+            gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            gms = float(gt.item()) * 1e3
+            gather = {"allgather_ms": round(gms, 3), "bytes_total": total * n * 44 * 4, "shape_ok": bool(ok),
+                      "value_with_allgather": round(total / (el / steps + gms * 1e-3), 1)}
+            del full
+        except Exception as e:
+            gather = {"error": f"{type(e).__name__}: {e}"[:200]}
+    res = {"metric": "PCG windows/sec FSST, corpus preprocessing (C3)", "value": round(total * steps / el, 1), "unit": "windows/s",
+           "n_gpus": world, "steps": steps, "warmup": max(warmup, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"C3: {nrec} synthetic recordings x {T} samples -> {total} windows of 2000 (stride 1000), "
+                                  "recording-level split over the ranks, frame-list launches of <= 4096 windows, Kaiser(128,0.5), "
+                                  "band [25,200] Hz, stack=True", "windows_this_rank": mine, "launches_per_step": len(groups),
+                      "parallelism": f"recording-sharded x{world}, ragged all-gather of the feature blocks"},
+           "roofline": {"bound": "hbm", "achieved": round(total * steps / el * BYTES_PER_WINDOW / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(total * steps / el * BYTES_PER_WINDOW / 1e9 / HBM_PEAK_GBS / max(world, 1), 5), "traffic": None,
+                        "note": "whole step (all launches and gaps) over the algorithmic bytes; per GPU"}}
+    if gather:
+        res["allgather"] = gather
+    if host_fed and world == 1:
+        q = nrec // 4
+        hrecs = [(torch.from_numpy(np.roll(base[i % 8], 97 * i)), None) for i in range(q)]
+        out = {}
+        builder = corpus.CorpusBuilder(tf, device=dev)
+        for keep in (True, False):
+            first = builder.build(hrecs, keep_on_device=keep)                 # allocates the staging buffers and the arena
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            items = builder.build(hrecs, keep_on_device=keep, out=first.features)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            out["device_kept" if keep else "host_returned"] = {"windows_per_s": round(len(items) / dt, 1), "seconds": round(dt, 4),
+                                                                "windows": len(items)}
+            del items, first
+        out["note"] = (f"corpus.CorpusBuilder.build from {q} HOST recordings (pageable float32), second call of a builder (staging "
+                       "buffers and the feature arena reused): pinned double-buffered uploads on a side stream, frame-list launches "
+                       "into the arena; host-returned = group-wise D2H into a pinned host arena on a third stream")
+        res["host_fed"] = out
+    return res
 
 
 def main():
@@ -171,7 +323,9 @@ def main():
                     help="extra untimed steps run BEFORE the W warm-up steps so the GPU reaches its sustained clocks "
                          "(a 20 ms burst from idle measures the clock ramp); counted in the reported `warmup`")
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU")
-    ap.add_argument("--config", choices=("c2", "c5"), default="c2")
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2")
+    ap.add_argument("--no-extras", action="store_true", help="c2 only: skip the C3 / C5 sub-measurements and the live PMC passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # a short c2 run under rocprofv3 --pmc
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -180,7 +334,8 @@ def main():
     if args.config == "c5":
         if args.gpus != 1:
             ap.error("--config c5 is a single-GPU measurement")
-        return bench_c5(args)
+        print(json.dumps(bench_c5(args.steps, args.warmup)), flush=True)
+        return
 
     # N > 1 without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1),
     # exactly as the driver would:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...
@@ -211,6 +366,14 @@ def main():
         world = dist.get_world_size()                      # what RCCL actually sees
     dev = torch.device("cuda", local)
 
+    if args.config == "c3":
+        res = bench_c3(dev, rank, world, use_dist, max(1, min(args.steps, 20)), min(args.warmup, 3))
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
     n, B = 2000, args.batch
     w = synth.kaiser_window(128, 0.5)
     Xh = synth.pcg_windows(B, n, seed=synth.SEED + rank)
@@ -237,6 +400,8 @@ def main():
     core_ms, norm_ms, ncalls = tf.timing(local)
     tf.set_timing(False, local)
     fused = tf.check(local)                                   # raises if a kernel reported a failed internal wait
+    if args.pmc_child:                                        # (under rocprofv3 --pmc: the parent reads the counters)
+        return
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,11 +434,17 @@ def main():
         alg = BYTES_PER_WINDOW * B
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         step_gbs = alg / (ms_per_step * 1e-3) / 1e9
-        kname = ("fsst_core128_kernel<16, 8, 64, true, 16, 3, true>" if fused else "fsst_core128_kernel<16, 8, 64, true, 16, 3, false>")
+        kname = {1: "fsst_core128_kernel<16, 8, 64, true, 16, 3, true>", 2: "fsst_team128_kernel<3>"}.get(fused, "fsst_core128_kernel<16, 8, 64, true, 16, 3, false>")
+        kdesc = {1: " (transform + z-score in one launch: one CU per signal, tile round-trips through HBM inside the launch)",
+                 2: " (transform + z-score in one launch: teams of CUs, features z-scored in registers and written once)"}.get(
+                     fused, " (transform; z-score is a second kernel)")
         prof = pmc_profile(kname) if B == 1024 else None
-        roof = {"bound": "hbm", "kernel": kname + (" (transform + z-score fused)" if fused else " (transform; z-score is a second kernel)"),
+        live = live_traffic(kname, B) if (world == 1 and not args.no_extras) else None
+        traffic = live["hbm_bytes_per_launch"] if live else (prof.get("hbm_bytes_per_launch") if prof else None)
+        roof = {"bound": "hbm", "kernel": kname + kdesc,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
+                "traffic": traffic,
+                "traffic_source": (live["how"] if live else ("profiles/r03_pmc.json (same sources, SHA-256 checked)" if prof else None)),
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom_ms, 4),
                 "other_kernels_avg_ms": round(norm_ms / max(ncalls, 1), 4), "launches_timed": ncalls,
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
@@ -284,23 +455,42 @@ def main():
             roof["fp32_frac"] = round(flop / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
             roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
                                  f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
-                                 f"per launch (profiles/r02_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
+                                 f"per launch (profiles/r03_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
         line = {
             "metric": "PCG windows/sec FSST (1 kHz, 2000-sample)", "value": round(value, 1),
-            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": untimed,
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2: {B} x {n} fp32 synthetic PCG windows per GPU, fs=1000, "
                                    "Kaiser(128,0.5), band [25,200] Hz, stack=True -> (2000,44) fp32",
-                       "windows_per_gpu": B, "warmup_requested": args.warmup, "clock_settle_steps": max(args.settle_steps, 0),
+                       "windows_per_gpu": B, "clock_settle_steps": max(args.settle_steps, 0),
+                       "untimed_steps_total": untimed,
                        "parallelism": f"window-sharded x{world}, no data-path collective",
-                       "zscore": "fused into the transform kernel" if fused else "second kernel"},
+                       "zscore": {1: "same launch (one CU per signal)", 2: "same launch (team kernel)"}.get(fused, "second kernel")},
             "roofline": roof,
         }
         if gather:
             line["allgather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Xh, w, args.cpu_budget)
+    # the other BASELINE configurations of the path, carried by the same line: C3 (corpus preprocessing, recording-level
+    # split, RCCL all-gather when N > 1) on every N, C5 (streaming) on one GPU
+    extras = {}
+    if not args.no_extras:
+        del out
+        try:
+            c3 = bench_c3(dev, rank, world, use_dist, 3, 1)
+            extras["c3"] = {k: c3[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "allgather", "host_fed", "roofline") if k in c3}
+        except Exception as e:                                   # never lose the bench line to a side measurement
+            extras["c3"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1:
+            try:
+                c5 = bench_c5(2000, 100)
+                extras["c5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "latency_host_visible_ms")}
+            except Exception as e:
+                extras["c5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -24,6 +24,11 @@ _lib = None
 hip_owner_pid = None     # pid of the process in which this package first touched HIP (inherited by forked children)
 
 
+class ForkedAfterGpuInitError(RuntimeError):
+    """A DataLoader worker forked after its parent initialised the GPU tried to use the transform (a RuntimeError, as the
+    reference's dataset expects, but also logged at ERROR and warned once: see ``guard_fork``)."""
+
+
 def guard_fork() -> None:
     """HIP cannot be used in a child forked AFTER the parent initialised it (the reference forks DataLoader workers,
     /root/reference/main.py:202-218).  Creating the plan lazily in the worker is fine -- that is the supported pattern;
@@ -31,17 +36,29 @@ def guard_fork() -> None:
     dataset catches, hss/datasets/heart_sounds.py:183) instead of undefined behaviour inside the driver."""
     global hip_owner_pid
     pid = os.getpid()
+
+    def refuse(msg: str):
+        # The reference's dataset catches RuntimeError, prints it and returns None (heart_sounds.py:183): with
+        # in_memory=False and num_workers > 0 every sample of such a worker becomes None and the failure surfaces later, in
+        # collate_fn.  Say it once, loudly, where it happens.
+        import logging
+        import warnings
+        logging.getLogger("heart_sounds_segmentation_amd").error(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        raise ForkedAfterGpuInitError(msg)
+
     if hip_owner_pid is not None and hip_owner_pid != pid:
-        raise RuntimeError("FSST: the HIP runtime was initialised in the parent process before this worker was forked; "
-                           "create / first use the transform inside the worker (lazy plan), or start workers with "
-                           "multiprocessing_context='spawn'")
+        refuse("FSST: the HIP runtime was initialised in the parent process before this worker was forked; "
+               "create / first use the transform inside the worker (lazy plan), or start workers with "
+               "multiprocessing_context='spawn'")
     try:
         import torch
-        if torch.cuda._is_in_bad_fork():
-            raise RuntimeError("FSST: torch initialised the GPU in the parent process before this worker was forked; "
-                               "use multiprocessing_context='spawn' or touch the GPU only inside the workers")
+        bad = torch.cuda._is_in_bad_fork()
     except (ImportError, AttributeError):
-        pass
+        bad = False
+    if bad:
+        refuse("FSST: torch initialised the GPU in the parent process before this worker was forked; "
+               "use multiprocessing_context='spawn' or touch the GPU only inside the workers")
     hip_owner_pid = pid
 
 

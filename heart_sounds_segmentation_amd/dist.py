@@ -6,10 +6,17 @@ on every rank for the consumer (the BiLSTM).  One process per GPU.
 The reference has no distributed code at all; this module is the
 build's single parallelism strategy.  ``compute`` is injected so that the sharding / gather logic
 is testable on CPU with the gloo backend (tests/test_dist.py).
+
+Where the exchange runs: RCCL moves device memory only, so under the ``nccl`` backend every tensor handed to a
+collective lives on this process's current GPU (host features are staged there first and the result stays there unless
+``out_device`` says otherwise); under ``gloo`` the tensors stay where they are.  Ragged blocks (the recording-level
+corpus split: a rank's window count depends on its recordings' lengths) are gathered STRAIGHT into the final buffer, one
+broadcast per non-empty rank into that rank's row range -- no padded copy, no concatenation; a rank that holds no
+rows takes part with an empty block.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -24,13 +31,21 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def comm_device(group: Optional[dist.ProcessGroup] = None, like: Optional[torch.Tensor] = None) -> torch.device:
+    """The device collectives of ``group`` must run on: this process's current GPU for RCCL (``nccl``), otherwise the
+    device of ``like`` (gloo moves host memory, and device memory through the host)."""
+    backend = str(dist.get_backend(group)).lower()
+    if "nccl" in backend:
+        return torch.device("cuda", torch.cuda.current_device())
+    return like.device if like is not None else torch.device("cpu")
+
+
 def sharded_features(compute: Callable[[torch.Tensor], torch.Tensor], X: torch.Tensor,
                      gather: bool = True, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """``X``: the FULL ``(B, n)`` batch, identical on every rank (e.g. read from shared storage).
     Each rank transforms only its block ``X[lo:hi]``.  ``gather=False`` returns the local block
     (features stay sharded, e.g. for data-parallel training); ``gather=True`` returns the full
-    ``(B, ...)`` feature batch on every rank via ONE all-gather (ragged tails padded to the
-    largest block, then trimmed)."""
+    ``(B, ...)`` feature batch on every rank via ONE all-gather."""
     if not (dist.is_available() and dist.is_initialized()):
         return compute(X)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -42,41 +57,85 @@ def sharded_features(compute: Callable[[torch.Tensor], torch.Tensor], X: torch.T
     return all_gather_blocks(local, B, group)
 
 
-def all_gather_blocks(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def all_gather_blocks(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-gather per-rank feature blocks (block split of ``total`` by ``shard_bounds``) into the
     full batch, in rank order.  Equal blocks: a single ``all_gather_into_tensor`` straight into the
-    result.  Ragged: pad to the largest block, gather once, trim."""
+    result; ragged: one broadcast per rank into its row range of the result."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [shard_bounds(total, world, r) for r in range(world)]
-    counts = [h - l for l, h in sizes]
+    counts = [h - l for l, h in (shard_bounds(total, world, r) for r in range(world))]
     if local.shape[0] != counts[rank]:
         raise ValueError(f"all_gather_blocks: local block has {local.shape[0]} rows, expected {counts[rank]}")
-    return _gather_counts(local, counts, group)
+    return _gather_counts(local, counts, tuple(local.shape[1:]), group, out)
 
 
-def all_gather_ragged(local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-    """All-gather blocks whose row counts are only known locally (recording-level corpus split: the number of
-    windows per rank depends on the recording lengths): one tiny all-gather of the counts, then the payload."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
+_DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int64, torch.int32, torch.uint8, torch.bool,
+           torch.complex64]
+
+
+def all_gather_ragged(local: Optional[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
+                      tail: Optional[Sequence[int]] = None, dtype: Optional[torch.dtype] = None,
+                      out_device: Optional[torch.device] = None) -> torch.Tensor:
+    """All-gather blocks whose row counts are only known locally (recording-level corpus split): one tiny all-gather
+    of {rows, trailing shape, dtype} per rank, then the payload straight into the result.  A rank without rows passes
+    ``local=None`` (or a 0-row tensor): it learns the trailing shape and dtype from the others."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if local is None:
+            raise ValueError("all_gather_ragged: nothing to gather (no process group, no block)")
+        return local if out_device is None else local.to(out_device)
     world = dist.get_world_size(group)
-    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    allc = torch.empty(world, dtype=torch.int64, device=local.device)
-    dist.all_gather_into_tensor(allc, mine, group=group)
-    return _gather_counts(local, [int(c) for c in allc.tolist()], group)
+    if local is not None:
+        tail, dtype = tuple(local.shape[1:]), local.dtype
+    tail = tuple(int(t) for t in (tail or ()))
+    if len(tail) > 6:
+        raise ValueError("all_gather_ragged: at most 6 trailing dimensions")
+    dev = comm_device(group, local)
+    code = _DTYPES.index(dtype) if dtype in _DTYPES else -1
+    rows = int(local.shape[0]) if local is not None else 0
+    known = 1 if (local is not None or tail) and code >= 0 else 0
+    mine = torch.tensor([rows, known, code, len(tail)] + list(tail) + [0] * (6 - len(tail)), dtype=torch.int64, device=dev)
+    meta = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(meta.view(-1), mine, group=group)
+    meta_l: List[List[int]] = meta.cpu().tolist()
+    counts = [int(m[0]) for m in meta_l]
+    src = next((m for m in meta_l if m[1] == 1 and m[0] > 0), None) or next((m for m in meta_l if m[1] == 1), None)
+    if src is None:
+        raise ValueError("all_gather_ragged: no rank knows the block shape (every rank is empty and none passed `tail`)")
+    tail, dtype = tuple(src[4:4 + src[3]]), _DTYPES[src[2]]
+    if local is None:
+        local = torch.empty((0,) + tail, dtype=dtype, device=dev)
+    elif tuple(local.shape[1:]) != tail or local.dtype != dtype:
+        raise ValueError(f"all_gather_ragged: this rank's block {tuple(local.shape)} {local.dtype} does not match "
+                         f"the others' trailing shape {tail} {dtype}")
+    full = _gather_counts(local, counts, tail, group, None)
+    return full if out_device is None else full.to(out_device)
 
 
-def _gather_counts(local: torch.Tensor, counts, group) -> torch.Tensor:
-    world, total = len(counts), sum(counts)
-    tail = tuple(local.shape[1:])
-    local = local.contiguous()
+def _gather_counts(local: torch.Tensor, counts: Sequence[int], tail: Tuple[int, ...], group,
+                   out: Optional[torch.Tensor]) -> torch.Tensor:
+    world, rank, total = len(counts), dist.get_rank(group), sum(counts)
+    dev = comm_device(group, local)
+    if out is None:
+        out = torch.empty((total,) + tuple(tail), dtype=local.dtype, device=dev)
+    elif tuple(out.shape) != (total,) + tuple(tail) or out.device != dev or out.dtype != local.dtype or not out.is_contiguous():
+        raise ValueError("gather: `out` must be a contiguous (total, ...) tensor of the block dtype on the communication device")
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    mine = out[offs[rank]: offs[rank + 1]]
+    if local.data_ptr() != mine.data_ptr() or local.device != dev:     # (a block computed in place in `out` needs no copy)
+        mine.copy_(local, non_blocking=True)
     if len(set(counts)) == 1:
-        out = torch.empty((total,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=group)
+        # (RCCL gathers in place when the send buffer is the rank's own slot of the receive buffer; gloo gets a copy)
+        dist.all_gather_into_tensor(out, mine if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() else mine.clone(),
+                                    group=group)
         return out
-    mx = max(counts)
-    padded = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
-    padded[: local.shape[0]] = local
-    buf = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, padded, group=group)
-    return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+    works = []
+    for r in range(world):
+        if counts[r] == 0:
+            continue
+        works.append(dist.broadcast(out[offs[r]: offs[r + 1]], src=dist.get_global_rank(group, r) if group is not None else r,
+                                    group=group, async_op=True))
+    for wk in works:
+        wk.wait()
+    return out

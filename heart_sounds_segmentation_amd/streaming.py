@@ -8,7 +8,8 @@ latency ``nwin/2 - 1`` samples) through ``hssfsst_exec_frames`` (no frame touche
 std of the real and imaginary blocks, kept on the device by ``hssfsst_moments_merge`` (the chunked
 form of ``hss.moments.update_mean / update_variance``, hss/moments/__init__.py:1-36).
 
-Concatenating the un-normalised outputs of consecutive steps (zero initial history) reproduces the
+Concatenating the un-normalised outputs of consecutive steps (zero initial history; ``step`` returns a fresh tensor
+unless called with ``copy=False``, which hands out the object's single output buffer) reproduces the
 offline transform's columns ``-nwin/2 + 1, ..`` exactly: column tau of the offline, zero-padded FSST
 is column ``tau + nwin/2 - 1`` of the stream.
 
@@ -57,6 +58,7 @@ class StreamingFSST:
         self._pin_in = None
         self._pin_out = None
         self._keep = None
+        self._pin_ring = None
 
     # kept for callers / tests that looked at the history of the first implementation
     @property
@@ -83,20 +85,37 @@ class StreamingFSST:
                    "hssfsst_stream_step")
         self.pos += self.chunk
 
-    def step(self, x_new: torch.Tensor) -> torch.Tensor:
+    def step(self, x_new: torch.Tensor, copy: bool = True) -> torch.Tensor:
         """``x_new``: ``(channels, chunk)`` newest samples (device tensor preferred).  Returns
         ``(channels, chunk, 2K)`` features of the columns centred ``nwin/2 - 1`` samples before the
-        newest sample and earlier.  The returned tensor is this object's output buffer: it is
-        overwritten by the next step."""
+        newest sample and earlier.
+
+        ``copy=True`` (default) returns a fresh tensor, so ``[st.step(x) for x in chunks]`` or ``torch.cat`` over collected
+        outputs behave as expected.  ``copy=False`` returns THIS OBJECT'S OUTPUT BUFFER, which the next step overwrites
+        (no allocation per step: the latency-critical loop of BASELINE config 5).
+        A host ``x_new`` is first copied into one of two pinned staging buffers of this object, so the caller may refill
+        its own buffer as soon as ``step`` returns (the upload itself is asynchronous)."""
         if tuple(x_new.shape) != (self.channels, self.chunk):
             raise ValueError(f"StreamingFSST.step: expected {(self.channels, self.chunk)}, got {tuple(x_new.shape)}")
+        if not x_new.is_cuda:
+            if self._pin_ring is None:
+                self._pin_ring = [torch.empty((self.channels, self.chunk), dtype=torch.float32).pin_memory() for _ in range(2)]
+                self._pin_ev = [torch.cuda.Event() for _ in range(2)]
+                self._pin_k = 0
+            k = self._pin_k
+            self._pin_ev[k].synchronize()                  # the upload that last read this staging buffer has finished
+            self._pin_ring[k].copy_(x_new)                 # (converts dtype / layout as needed)
+            self._native_step(self._pin_ring[k].data_ptr(), self.chunk, False, None)
+            self._pin_ev[k].record(torch.cuda.current_stream(self.device))
+            self._pin_k = k ^ 1
+            return self.out.clone() if copy else self.out
         if x_new.dtype != torch.float32 or x_new.stride(1) != 1 or x_new.stride(0) < self.chunk:
             x_new = x_new.to(torch.float32).contiguous()   # (a column slice of a wider row-major tensor is taken as it is)
-        if x_new.is_cuda and x_new.device != self.device:
+        if x_new.device != self.device:
             x_new = x_new.to(self.device)
-        self._native_step(x_new.data_ptr(), x_new.stride(0), x_new.is_cuda, None)
+        self._native_step(x_new.data_ptr(), x_new.stride(0), True, None)
         self._keep = x_new                                 # the copy is asynchronous: keep the source alive until the next step
-        return self.out
+        return self.out.clone() if copy else self.out
 
     def step_unfused(self, x_new: torch.Tensor) -> torch.Tensor:
         """The same step as separate calls (copy, ``hssfsst_exec_frames``, ``hssfsst_moments_merge``,

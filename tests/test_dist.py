@@ -84,6 +84,30 @@ def test_all_gather_ragged_world2(tmp_path):
     assert np.array_equal(a, want) and np.array_equal(b, want)
 
 
+def _empty_rank_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heart_sounds_segmentation_amd import corpus
+    # rank 1 holds nothing (e.g. its block of recordings is all shorter than a frame): it must still take part
+    local = (torch.arange(3 * 2 * 5, dtype=torch.float32).reshape(3, 2, 5) if rank == 0 else None)
+    full = hdist.all_gather_ragged(local)
+    items = corpus.FrameItems(local if local is not None else torch.empty((0, 2, 5)), None)
+    full2 = corpus.gather_features(items)
+    np.save(os.path.join(tmp, f"empty{rank}.npy"), torch.stack([full, full2]).numpy())
+    dist.destroy_process_group()
+
+
+def test_all_gather_ragged_with_an_empty_rank(tmp_path):
+    """A rank without rows (world > usable recordings, or a block of too-short recordings) joins the collectives with a
+    0-row block and learns shape and dtype from the others (round 2 raised on that rank while its peers hung)."""
+    mp.spawn(_empty_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.arange(30, dtype=np.float32).reshape(3, 2, 5)
+    for r in range(2):
+        got = np.load(tmp_path / f"empty{r}.npy")
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 # The N > 1 path with the HIP kernels as the per-rank compute.  A gpurun box has ONE GPU and RCCL refuses two
 # ranks on one device, so both ranks drive cuda:0 and the exchange runs over gloo (features staged to the host);
@@ -138,3 +162,40 @@ def test_sharded_hip_compute_world2(tmp_path):
     assert n0 + n1 == want.shape[0] and n0 > 0 and n1 > 0
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"c3_{r}.npy"), want)
+
+
+def _rccl_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from heart_sounds_segmentation_amd import FSST, corpus
+    tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True, device="cuda:0")
+    recs = _corpus([5200, 1500, 7300, 4100], seed=33)
+    out = {}
+    for keep in (False, True):                                            # host-returned (the default) and device-kept features
+        items = corpus.build_features(recs, tf, rank=rank, world=world, keep_on_device=keep, windows_per_launch=4)
+        feats = corpus.gather_features(items)                             # RCCL: runs -- and stays -- on the GPU
+        assert feats.is_cuda and feats.shape == (3 + 5 + 2, 2000, 44)
+        out[keep] = feats.cpu()
+        assert torch.equal(out[keep], items.features.cpu())
+    assert torch.equal(out[False], out[True])
+    blk = hdist.all_gather_blocks(out[True].cuda(), out[True].shape[0])   # equal-block path (in-place RCCL all-gather)
+    assert torch.equal(blk.cpu(), out[True])
+    host = corpus.gather_features(items, out_device=torch.device("cpu"))
+    assert not host.is_cuda and torch.equal(host, out[True])
+    np.save(os.path.join(tmp, "rccl.npy"), out[True].numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_corpus_gather_over_rccl_one_rank(tmp_path):
+    """The C3 exchange on the backend north_star names: a 1-rank RCCL process group (what one gpurun box can host) with
+    host-returned AND device-kept features -- round 2 handed CPU tensors to the RCCL collective and had only ever run
+    over gloo.  Features equal the single-process builder's."""
+    from heart_sounds_segmentation_amd import FSST, corpus
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True, device="cuda:0")
+    items = corpus.build_features(_corpus([5200, 1500, 7300, 4100], seed=33), tf)
+    assert np.array_equal(np.load(tmp_path / "rccl.npy"), items.features.numpy())
