@@ -1,0 +1,663 @@
+// fsst_canon128.hpp -- the transform for the reference's own configuration class: nwin = 128, time-major [re | im]
+// output (FSST(stack=True), /root/reference/hss/transforms/synchrosqueeze.py:61-63,67-89) and a kept band that is a
+// COMPILE-TIME constant (KLO, KC) inside rows 0..31 -- the canonical [25, 200] Hz at fs = 1000 of
+// /root/reference/main.py:153-158 is (4, 22).  Every other configuration keeps fsst_core128_kernel (fsst_mfma128.hpp); the
+// algorithm (oracle/fsst_oracle.c steps 1-7) and the rounding-tie machinery are the same, what changes is the cost:
+//
+//  * the window fold (window multiply + first radix-8 stage, 32 v_mfma_f32_16x16x4_f32 per 16 frames = 27 % of the
+//    round-2 kernel's issue time) runs on the 16-bit matrix pipe with SPLIT operands: every sample and every constant is
+//    a pair of halves, x = x1 + x2, c = c1 + c2 (22 significant bits each, scaled by powers of two into the middle of the
+//    f16 range), and the four products x1 c1, x1 c2, x2 c1, x2 c2 of the 8 fold terms are exactly the K = 32 of ONE
+//    v_mfma_f32_16x16x32_f16 per tap (fp32 accumulation; the products of two halves are exact in it).  Error per term
+//    <= 2^-22 |x c| -- the same order as the fp32 FMA chain it replaces -- and every rounding decision that float32
+//    cannot make is still made in float64 from the signal's own float32 samples (canon_resolve reads them from HBM).  The tile of a group is the ALIGNED
+//    64-frame window of its signal whatever kernel or chunking processes it, so the power-of-two scale -- and with it every
+//    bit of the result -- does not depend on the path (two-launch, one CU per signal, team);
+//  * the band is a constant: the own plane covers rows 4 floor(KLO / 4) .. only (24 instead of 32 columns: that is what
+//    pays for the 8-byte sample records and the 16 kB operand table in LDS), sources whose half-stripe holds no kept row
+//    are not stored, the statistics and the wide-store pass are straight-line code, and a source that is `need` rows
+//    away from the band (or its negative-frequency twin) takes the rare path only when |shift| >= need - 1/2 (less a
+//    margin): a source that moves without reaching the band changes nothing, which for the canonical band takes the
+//    upper half of the spectrum out of the rare path altogether.
+#pragma once
+#include "fsst_mfma128.hpp"
+
+namespace hssfsst {
+
+using h8 = _Float16 __attribute__((ext_vector_type(8)));
+using u2 = unsigned __attribute__((ext_vector_type(2)));
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+using lds_u2 = __attribute__((address_space(3))) u2;
+using lds_u4 = __attribute__((address_space(3))) u4;
+
+constexpr int kCanonTileFrames = 64;                     // frames per aligned tile (4 groups = one statistics block)
+constexpr int kCanonRecs = 192;                          // sample records per tile: 64 + 127, rounded up
+constexpr int kCanonAtabFloats = 16 * 64 * 4;            // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
+constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
+// Rounding ties of this kernel: no queues.  A cell whose float32 coordinate is too close to a half-integer sets ONE BIT of a
+// per-group bitmap in LDS -- bit 16 (k' & 1) + frame of word k' >> 1, k' = 0..63 -- so the number of undecided cells of a
+// group is not limited by anything (the queues of fsst_core128_kernel hold 240 + 24 and fall back to float32 beyond that:
+// tonal and offset-dominated inputs under low-sidelobe windows overflowed them, profiles/r02_adversarial_parity.txt class
+// iii), and the bitmap is a sixth of their size.  Resolution (canon_resolve): up to kTieCoop cells one by one with the whole
+// wave on one float64 DFT; more than that, lane l takes source k' = l and walks its 16 frame bits.  The float32 V of a cell
+// inside the stored cover is read back from -- and cleared in -- its own column; for a cell outside it V is the float64
+// DFT's own result (rounded once), so nothing has to be carried along.
+constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
+
+template <int KLO, int KC>
+struct CanonCfg {
+    static_assert(KC % 2 == 0 && KC >= 2 && KC <= 24 && KLO >= 0 && KLO + KC <= 32, "even band of <= 24 rows inside rows 0..31");
+    static constexpr int NWIN = 128;
+    static constexpr int KHI = KLO + KC - 1;
+    static constexpr int H0 = KLO / 4, H1 = KHI / 4;                 // half-stripes (4 rows) that hold kept rows
+    static constexpr int COV0 = 4 * H0, COVN = 4 * (H1 - H0 + 1);    // the own plane's columns: rows COV0 .. COV0 + COVN - 1
+    static constexpr int LD = odd_up(COVN + 1), LDF = plane_ldf(KC), KOFF = KLO - COV0;
+    // lane group g holds classes rA = g and rB = (g ? 8 - g : 4): the A source of stripe s sits in half-stripe 2 s (rows
+    // 8 s .. 8 s + 3), the B source in half-stripe 2 s + 1
+    static constexpr bool stored(int s, int half) { return 2 * s + half >= H0 && 2 * s + half <= H1; }
+    static constexpr int need_row(int row)               // rows between `row` and the nearest kept row or twin of one (cyclic)
+    {
+        int best = NWIN;
+        for (int k = KLO; k <= KHI; ++k)
+            for (int tw = 0; tw < 2; ++tw) {
+                const int r = tw ? (NWIN - k) % NWIN : k;
+                int d = row > r ? row - r : r - row;
+                if (NWIN - d < d) d = NWIN - d;
+                if (d < best) best = d;
+            }
+        return best;
+    }
+    static constexpr int need(int s, int half)
+    {
+        int best = NWIN;
+        for (int r = 0; r < 4; ++r) {
+            const int d = need_row(8 * s + 4 * half + r);
+            if (d < best) best = d;
+        }
+        return best;
+    }
+    // |shift| from which the source may change a kept row; below it the source is left alone (exact: it cannot reach the
+    // band).  The margin hands coordinates within (1 + need) / 64 of the deciding half-integer to the rare path, whose
+    // error bound then decides between float32 and float64.
+    static constexpr float thr(int s, int half)
+    {
+#ifdef HSS_NO_TIES
+        return need(s, half) <= 1 ? 0.5f : static_cast<float>(need(s, half)) - 0.5f;
+#else
+        const int nd = need(s, half);
+        return (nd <= 1 ? 0.5f : static_cast<float>(nd) - 0.5f) - static_cast<float>(1 + (nd <= 1 ? 0 : nd)) * kTieMargin;
+#endif
+    }
+    static constexpr int wave_floats() { return 2 * kCanonRecs + 2 * 16 * (LD + LDF) + 4 + kCanonTieWords; }
+};
+
+// Host side of the f16 operand table: entry (tap n, lane l, half h): lane l = (kk, row i); h -> fold term q = 2 kk + (h >> 2),
+// product h & 3 = {x1 c1, x1 c2, x2 c1, x2 c2} -> the constant's half c1 (h even) or c2 (h odd).  Row i -> (class, re / im) as
+// in the fp32 table of fsst_core128_kernel.  `cs` = 2^sc scales the constants into [2^13, 2^14).
+// (built in hssfsst.hip: canon_build_atab)
+
+// One tile's scale, as the kernels hand it around (wave-uniform).
+struct CanonTile {
+    float R2s;            // error-bound scale of the tile in SCALED units (see "Rounding ties" in fsst_mfma128.hpp)
+    float inv;            // 1 / (sample scale x constant scale): features = plane values x inv (a power of two)
+};
+
+// Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile, zero outside the signal)
+// as records {x1 | x1 << 16, x2 | x2 << 16} and returns the scales.  The scale exponent comes from the tile's energy
+// (max |x| <= sqrt(sum x^2) < 2^hb => |x| 2^(14 - hb) < 2^14 < 65504), which the error bound needs anyway.
+__device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec, float r2scale_s, float inv_c, int lane)
+{
+    float e2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e2 = fmaf(sreg[k], sreg[k], e2);
+    const float E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+    const int eb = static_cast<int>((__float_as_uint(E) >> 23) & 0xffu);          // biased exponent (0: zero / denormal tile)
+    const int hb = (eb - 127 + 2) >> 1;                                             // sqrt(E) < 2^hb
+    const int se = (eb == 0 || eb == 255) ? 127 : 127 + 14 - hb;                    // biased exponent of the sample scale
+    const float sx = __uint_as_float(static_cast<unsigned>(se) << 23);
+    CanonTile t;
+    t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
+    t.R2s = r2scale_s * (E * sx) * sx;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = sreg[k] * sx;
+        const _Float16 x1 = static_cast<_Float16>(v);
+        const _Float16 x2 = static_cast<_Float16>(v - static_cast<float>(x1));
+        const unsigned b1 = __builtin_bit_cast(unsigned short, x1), b2 = __builtin_bit_cast(unsigned short, x2);
+        xrec[lane + 64 * k] = u2{b1 | (b1 << 16), b2 | (b2 << 16)};      // (lane + 128 < kCanonRecs: no predicate)
+    }
+    wave_sync();
+    return t;
+}
+
+// Rare path of a displaced source (oracle/fsst_oracle.c steps 4-6 in float32), as displaced_source of fsst_mfma128.hpp
+// with the bitmap instead of the queues.  `row_disp` = this lane's frame row of the displaced plane.
+template <int KLO, int KC>
+__device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigned* tb, int kpi, int j, float num, float den, f2 V,
+                                                float R2, f2* own_cell, bool stored)
+{
+    constexpr int NWIN = 128;
+    float shift = num * __builtin_amdgcn_rcpf(den);
+    if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
+    const float a = static_cast<float>(kpi) + shift;
+    float fr = a - floorf(a) - 0.5f;
+    const float s1 = 1.0f + fabsf(shift);
+    asm volatile("" : "+v"(fr));                        // (see displaced_source: keeps the two product chains unpacked)
+#ifndef HSS_NO_TIES
+    if (fr * fr * den < (kTieErr2 * kCanonErrMul) * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
+        __hip_atomic_fetch_or(tb + (kpi >> 1), 1u << (((kpi & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        flag[1] = 1;
+        return;
+    }
+#endif
+    const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
+    move_source<NWIN, true>(row_disp, flag, KLO, KC, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
+}
+
+// One undecided cell (k', frame jf) with its float64 spectrum values V = (vr, vi), Vd' = (dr, di) (true units, no sign):
+// the float64 coordinate rounded half away from zero, then the move.  plane_scale = 1 / tile.inv.
+template <int KLO, int KC>
+__device__ __forceinline__ void canon_resolve_one(f2* disp_base, int* flag, f2* own_base, int kpi, int jf,
+                                                  double vr, double vi, double dr, double di, double plane_scale)
+{
+    using C = CanonCfg<KLO, KC>;
+    constexpr int NWIN = 128;
+    const double den = vr * vr + vi * vi;
+    double shift = (dr * vi - di * vr) / den;
+    if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
+    const double a = static_cast<double>(kpi) + shift;
+    const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+    const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
+    const int h = kpi >> 2;
+    if (h >= C::H0 && h <= C::H1) {                      // inside the stored cover: the float32 V sits in its own column
+        f2* cell = own_base + jf * C::LD + (kpi - C::COV0);
+        const f2 V = *cell;
+        move_source<NWIN, true>(disp_base + jf * C::LDF, flag, KLO, KC, kpi, row, V, cell, true);
+    } else {
+        const double sg = (kpi & 1) ? -plane_scale : plane_scale;                   // the plane holds (-1)^k' V[k'], scaled
+        const f2 V = {static_cast<float>(vr * sg), static_cast<float>(vi * sg)};
+        move_source<NWIN, true>(disp_base + jf * C::LDF, flag, KLO, KC, kpi, row, V, nullptr, false);
+    }
+}
+
+template <int KLO, int KC, class Sample>
+__device__ __forceinline__ void canon_resolve(unsigned* tb, Sample sample, f2* disp_base, int* flag, f2* own_base,
+                                              const double* wtab, const double* twtab, double plane_scale, int lane)
+{
+    constexpr int NWIN = 128;
+    unsigned w = (lane < 32) ? tb[lane] : 0u;
+    int total = __popc(w);
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) total += __shfl_xor(total, off);
+    total = __builtin_amdgcn_readfirstlane(total);
+    if (total <= kTieCoop) {
+        // few cells: one by one, all lanes on one cell (two taps per lane, float64 butterfly sum)
+        for (int it = 0; it < total; ++it) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(w != 0u);
+            const int l0 = __builtin_ctzll(mask);
+            const unsigned ww = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), l0));
+            const int bit = __builtin_ctz(ww);
+            if (lane == l0) w &= w - 1u;
+            const int kpi = 2 * l0 + (bit >> 4), jf = bit & 15;
+            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+            for (int n = lane; n < NWIN; n += 64) {
+                const double x = sample(jf + n);
+                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+                const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+                const double xw = x * wd.x, xd = x * wd.y;
+                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
+                dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
+            }
+            if (lane == 0) canon_resolve_one<KLO, KC>(disp_base, flag, own_base, kpi, jf, vr, vi, dr, di, plane_scale);
+        }
+    } else {
+        // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = l and walks
+        // the frames whose bit is set -- at most 16 rounds, every round a full float64 DFT per lane
+        unsigned hw = (tb[lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
+        while (__builtin_amdgcn_ballot_w64(hw != 0u) != 0ull) {
+            const bool act = hw != 0u;
+            const int jf = act ? __builtin_ctz(hw) : 0;
+            hw &= hw - 1u;
+            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll 8
+            for (int n = 0; n < NWIN; ++n) {
+                const double x = sample(jf + n);
+                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+                const double2 cs = reinterpret_cast<const double2*>(twtab)[(lane * n) & (NWIN - 1)];
+                const double xw = x * wd.x, xd = x * wd.y;
+                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+            }
+            if (act) canon_resolve_one<KLO, KC>(disp_base, flag, own_base, lane, jf, vr, vi, dr, di, plane_scale);
+        }
+    }
+    if (lane < 32) tb[lane] = 0u;
+    if (lane == 0) flag[1] = 0;
+}
+
+// The group's transform up to and including the scatter: on return the own plane [16][LD] holds the group's synchrosqueezed
+// rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
+// xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
+// the group's first output column, for the float64 tie path.
+template <int KLO, int KC>
+__device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
+                                            const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
+                                            const float* xsig, int n, int tg)
+{
+    using C = CanonCfg<KLO, KC>;
+    constexpr int NT = 16, RQ = 8, NWIN = 128;
+    const int g = lane_o >> 4, j = lane_o & 15;
+    // lane (kk = g, f = j) is row-block kk of the B operand for frame f: records f + tap + 32 kk and + 16 (fold terms 2 kk, 2 kk + 1)
+    unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u2*)(xrec + j + 32 * g)));
+    unsigned aaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u4*)(reinterpret_cast<const u4*>(atab) + lane_o)));
+    asm volatile("" : "+v"(xaddr), "+v"(aaddr));
+    const lds_u2* xb = (const lds_u2*)static_cast<size_t>(xaddr);
+    const lds_u4* ab = (const lds_u4*)static_cast<size_t>(aaddr);
+    int pair = g;
+    asm volatile("" : "+v"(pair));
+    const bool isg0 = (pair == 0);
+    const int rAi = pair, rBi = isg0 ? RQ / 2 : RQ - pair;
+
+    f2 za[NT], zb[NT];
+    // (four taps at a time: all 16 are independent, and left alone the scheduler loads every operand first -- 128 registers)
+    static_for<NT / 4>([&](auto GG) {
+        constexpr int g0 = decltype(GG)::value * 4;
+        u4 a[4], b[4];
+        static_for<4>([&](auto I) {
+            constexpr int n = g0 + decltype(I)::value;
+            const u2 b0 = xb[n], b1 = xb[n + 16];
+            b[n - g0] = u4{b0.x, b0.y, b1.x, b1.y};
+            a[n - g0] = ab[n * 64];
+        });
+        static_for<4>([&](auto I) {
+            constexpr int n = g0 + decltype(I)::value;
+            const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[n - g0]), __builtin_bit_cast(h8, b[n - g0]),
+                                                                  f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            za[bitrev_n<NT>(n)] = f2{acc.x, acc.y};
+            zb[bitrev_n<NT>(n)] = f2{acc.z, acc.w};
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    fft_n<NT>(za);
+    fft_n<NT>(zb);
+
+    // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
+    unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
+    unsigned ob = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rBi - C::COV0)));
+    asm volatile("" : "+v"(oa), "+v"(ob));
+    lds_float* ownA = (lds_float*)static_cast<size_t>(oa);
+    lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
+    f2* row_disp = disp_base + j * C::LDF;
+    static_for<NT / 2>([&](auto SS) {
+        constexpr int s = decltype(SS)::value;
+        constexpr bool STA = C::stored(s, 0), STB = C::stored(s, 1);
+        constexpr float TA = C::thr(s, 0), TB = C::thr(s, 1);
+        const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
+        const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
+        const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+        const f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
+        const f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
+        const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
+        if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; }
+        if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; }
+        const bool ma = fabsf(dna.y) >= TA * dna.x, mb = fabsf(dnb.y) >= TB * dnb.x;
+        if (ma | mb) {
+            f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
+            f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
+            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, cellA, STA);
+            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, cellB, STB);
+        }
+    });
+    wave_sync();
+    int f_dirty = flag[0];
+    const int f_ties = flag[1];
+    if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
+        // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
+        // 1e-5 bins from a half-integer needs all 24
+        canon_resolve<KLO, KC>(reinterpret_cast<unsigned*>(tq), [&](int i) -> double {
+            const int gi = tg + i - NWIN / 2;
+            return (gi >= 0 && gi < n) ? static_cast<double>(xsig[gi]) : 0.0;
+        }, disp_base, flag, own_base, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        wave_sync();
+        f_dirty = flag[0];
+    }
+    if (__builtin_amdgcn_readfirstlane(f_dirty) != 0) {      // (rare) fold the displaced plane into the own plane, clear it
+        f2* src = own_base + j * C::LD + C::KOFF + g;
+        f2* dsp = disp_base + j * C::LDF + g;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (4 * u < KC && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
+        if (lane_o == 0) *flag = 0;
+        wave_sync();
+    }
+}
+
+// Statistics partial of the group in the own plane (see "Statistics" in fsst_kernels.hpp): pivoted sums over the kept cells
+// of the nvalid valid frames, computed on the SCALED plane values and scaled back afterwards -- a power of two, so the
+// result is the one the unscaled cells would give.  Returns piece_sums' w (row q of the wave: S1re / S2re / S1im / S2im)
+// and the pivot, both in feature units.
+template <int KLO, int KC>
+__device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, float inv, int lane_o, f2& piv_out)
+{
+    using C = CanonCfg<KLO, KC>;
+    const int g = lane_o >> 4, j = lane_o & 15;
+    const f2* src = own_base + j * C::LD + C::KOFF + g;
+    const f2 piv = own_base[C::KOFF];                    // frame 0, row KLO: one address, broadcast
+    constexpr int NU = (KC + 3) / 4, UF = KC / 4;        // rows g + 4 u: u < UF valid in every lane group, u == UF for g < KC - 4 UF
+    f2 v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = src[4 * u];
+    f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};
+    if (nvalid == 16) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f2 d = v[u] - piv;
+            if (u >= UF) { const bool ok = g + 4 * u < KC; d = f2{ok ? d.x : 0.0f, ok ? d.y : 0.0f}; }
+            st_s += d; st_q = pk_fma(d, d, st_q);
+        }
+    } else {
+        const bool jv = j < nvalid;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f2 d = v[u] - piv;
+            const bool ok = jv && (g + 4 * u < KC);
+            d = f2{ok ? d.x : 0.0f, ok ? d.y : 0.0f};
+            st_s += d; st_q = pk_fma(d, d, st_q);
+        }
+    }
+    float w = piece_sums(st_s.x, st_q.x, st_s.y, st_q.y);
+    w *= ((lane_o >> 4) & 1) ? inv * inv : inv;
+    piv_out = piv * f2{inv, inv};
+    return w;
+}
+
+// The group's image [16][2 KC] as this lane's three lane-linear float4s (float4 number lane + 64 i), in feature units.
+// ppk = the wide-store offset table in LDS ([3][64] words, two 16-bit byte offsets each: canon_store_offsets).
+template <int KLO, int KC>
+__device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* ppk, float inv, int lane_o, f4 (&o)[3])
+{
+    unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
+    asm volatile("" : "+s"(obase));                      // ONE scalar base: each cell is then "offset + base", no second add
+    const f2 sc = {inv, inv};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const unsigned pk = ppk[i * 64 + lane_o];
+        const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
+        const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
+        const f2 lo = f2{q0[0], q0[2]} * sc, hi = f2{q1[0], q1[2]} * sc;
+        o[i] = f4{lo.x, lo.y, hi.x, hi.y};
+    }
+}
+
+// Byte offsets, inside the own plane, of the two (re, re) / (im, im) pairs of float4 number f = lane + 64 i of a group's
+// contiguous [16][2 KC] image; packed lo | hi << 16.  (A pair's second element is the next cell: + 8 bytes.)
+template <int KLO, int KC>
+__device__ __forceinline__ unsigned canon_store_offsets(int f)
+{
+    using C = CanonCfg<KLO, KC>;
+    constexpr int Q = KC / 2;
+    const int jj = min(f / Q, 15), c = 4 * (f - (f / Q) * Q);
+    const int rowb = jj * C::LD + C::KOFF;
+    const unsigned p0 = (c < KC) ? (rowb + c) * 8 : (rowb + c - KC) * 8 + 4;
+    const unsigned p1 = (c + 2 < KC) ? (rowb + c + 2) * 8 : (rowb + c + 2 - KC) * 8 + 4;
+    return p0 | (p1 << 16);
+}
+
+struct CanonParams {
+    const float* x;       // [nsig][xstride]
+    float* out;           // [nsig][ncols][2 KC]
+    float* partials;      // two-launch path: [nsig][groups][kPartFloats]
+    const float* atab;    // f16 operand table (kCanonAtabFloats floats)
+    const double* wtab;   // float64 {w, dw'}[128]          } rounding-tie path
+    const double* twtab;  // float64 {cos, sin}(2 pi m / 128) }
+    float r2scale_s;      // r2scale of the plan x (constant scale)^2
+    float inv_c;          // 1 / constant scale
+    int n, mode, nsig, col0, ncols;
+    long long xstride;
+    Core128Regions reg;
+    unsigned* status;     // FUSED: device status word
+};
+
+constexpr int kCanonCtlFloats = 16 + 192;                            // [0] work counter, [16..207] wide-store offsets
+constexpr int kCanonCtlFusedFloats = kCtlFusedFloats;                // the layout of fsst_core128_kernel<FUSED>
+
+// The three samples per lane of the aligned tile that starts at output column t0 (xpad index t0 + i <-> sample t0 + i - 64).
+__device__ __forceinline__ void canon_fetch(const float* xsig, int n, int t0, int lane_o, float (&sreg)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int gi = t0 + lane_o + 64 * k - 64;
+        sreg[k] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fsst_canon_kernel: work distribution, tickets and the FUSED z-score exactly as fsst_core128_kernel (see there:
+// "Work distribution", "Fused z-score"); the body of a transform chunk is canon_group + canon_stats + canon_image.
+// ------------------------------------------------------------------------------------------------
+template <int KLO, int KC, bool FUSED>
+__global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonParams p)
+{
+    using C = CanonCfg<KLO, KC>;
+    constexpr int WPB = 16, K = KC, GPCF = kCanonTileFrames / 16;
+    constexpr int ATAB = kCanonAtabFloats;
+    constexpr int CTL = FUSED ? kCanonCtlFusedFloats : kCanonCtlFloats;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = p.n;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* atab = smem;
+    int* next_q = reinterpret_cast<int*>(smem + ATAB);
+    unsigned* done_a = reinterpret_cast<unsigned*>(smem + ATAB) + 1;
+    unsigned* dead = done_a + 2;
+    unsigned* ready = dead + 1;
+    float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + 272);
+    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);
+    unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + (FUSED ? 80 : 16));
+    float* part_lds = smem + ATAB + 288;
+    float* wbase = smem + ATAB + CTL + wv * C::wave_floats();
+    u2* xrec = reinterpret_cast<u2*>(wbase);
+    f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
+    f2* disp_base = own_base + 16 * C::LD;
+    int* flag = reinterpret_cast<int*>(disp_base + 16 * C::LDF);
+    int* tq = flag + 4;
+
+    for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
+    const int ncols = p.ncols, cend = p.col0 + p.ncols;
+    for (int i = lane; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+    if (lane < 4) flag[lane] = 0;
+    if (lane < kCanonTieWords) tq[lane] = 0;
+    if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
+    if (wv == 0) {
+        unsigned cls = 0u;                               // bit 2i / 2i+1: the first / second pair of float4 i is imaginary
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned c = (4u * static_cast<unsigned>(lane + 64 * i)) % static_cast<unsigned>(2 * K);
+            cls |= (c >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i);
+            cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
+            ppk_lds[i * 64 + lane] = canon_store_offsets<KLO, KC>(lane + 64 * i);
+        }
+        if constexpr (FUSED) cls_lds[lane] = cls;
+    }
+    __syncthreads();
+
+    const int nc0 = p.nsig * p.reg.npc[0];
+    const int nc1 = nc0 + p.nsig * p.reg.npc[1];
+    const int nchunks = nc1 + p.nsig * p.reg.npc[2];
+    const int ngroups = (ncols + 15) >> 4;
+    const int nk = (FUSED && p.nsig > static_cast<int>(blockIdx.x)) ? (p.nsig - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : 0;
+    const int NC = (ngroups + GPCF - 1) / GPCF;
+    const int lead = min(8, NC);
+    const int nwork = FUSED ? 2 * NC * nk : nchunks;
+    auto draw = [&]() -> int {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if constexpr (FUSED) return q < nwork ? q : nwork;
+        const long long c = static_cast<long long>(blockIdx.x) + static_cast<long long>(q) * gridDim.x;
+        return c < nwork ? static_cast<int>(c) : nwork;
+    };
+    int chunk = draw();
+    f2 tiny = {1.0e-37f, 0.0f};
+    asm volatile("" : "+s"(tiny));
+    while (chunk < nwork) {
+    long long b;
+    int grp0, ngrp;
+    long long ksig = 0;
+    bool zpass = false;
+    if constexpr (FUSED) {
+        int c;
+        if (chunk < NC) {
+            ksig = 0; c = chunk;
+        } else {
+            const int u = chunk - NC;
+            const int kk = 1 + u / (2 * NC), v = u - (kk - 1) * (2 * NC);
+            if (kk < nk) {
+                const int npairs = NC - lead;
+                if (v < lead) { ksig = kk; c = v; }
+                else if (v - lead < 2 * npairs) {
+                    const int w = v - lead;
+                    if (w & 1) { ksig = kk; c = lead + (w >> 1); }
+                    else { ksig = kk - 1; c = w >> 1; zpass = true; }
+                } else { ksig = kk - 1; c = npairs + (v - lead - 2 * npairs); zpass = true; }
+            } else { ksig = nk - 1; c = v; zpass = true; }
+        }
+        b = static_cast<long long>(blockIdx.x) + ksig * gridDim.x;
+        grp0 = c * GPCF;
+        ngrp = min(GPCF, ngroups - grp0);
+    } else {
+        const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
+        const int local = chunk - ((rg == 0) ? 0 : (rg == 1) ? nc0 : nc1);
+        const int npc = p.reg.npc[rg], gpc = p.reg.gpc[rg];
+        b = local / npc;
+        const int cidx = local - static_cast<int>(b) * npc;
+        grp0 = p.reg.g0[rg] + cidx * gpc;
+        ngrp = min(gpc, ngroups - grp0);
+    }
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    if (FUSED && zpass) {
+        // ---- B(ksig, c): z-score of ngrp groups of a signal whose statistics are (about to be) in LDS
+        const int sl = static_cast<int>(ksig) & 3;
+        const unsigned epoch = static_cast<unsigned>(ksig) + 1u;
+        constexpr int CC = 2 * K;
+        float4* d4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * CC) + lane_o;
+        constexpr int per = 8 * K;
+        for (unsigned spins = 0;; ++spins) {
+            unsigned have = 0;
+            if (lane == 0) have = __hip_atomic_load(ready + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(have) == epoch) break;
+            if (spins >= kSpinLimit || __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if (lane == 0) {
+                    __hip_atomic_store((gu32*)(p.status), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float4 st = fin_stats[sl];
+        const unsigned cls = cls_lds[lane_o];
+        const float4* base0 = reinterpret_cast<const float4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * CC);
+        auto glim = [&](int q) { return (q < ngrp) ? min(16, ncols - (grp0 + q) * 16) * (K >> 1) : 0; };
+        {
+            f4 o[GPCF][3];
+#pragma unroll
+            for (int q = 0; q < GPCF; ++q) {
+                const int lim = glim(q);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float4* src = (lane_o + 64 * i < lim) ? (d4 + q * per + 64 * i) : base0;
+                    o[q][i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+                }
+            }
+            f2 mu[3][2], rs[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
+                const float m0 = im0 ? st.z : st.x, r0 = im0 ? st.w : st.y;
+                const float m1 = im1 ? st.z : st.x, r1 = im1 ? st.w : st.y;
+                mu[i][0] = f2{m0, m0}; rs[i][0] = f2{r0, r0};
+                mu[i][1] = f2{m1, m1}; rs[i][1] = f2{r1, r1};
+            }
+#pragma unroll
+            for (int q = 0; q < GPCF; ++q) {
+                const int lim = glim(q);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (lane_o + 64 * i < lim) {
+                        const f2 lo = (f2{o[q][i].x, o[q][i].y} - mu[i][0]) * rs[i][0];
+                        const f2 hi = (f2{o[q][i].z, o[q][i].w} - mu[i][1]) * rs[i][1];
+                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + q * per + 64 * i));
+                    }
+                }
+            }
+        }
+    } else {
+    const float* xsig = p.x + b * p.xstride;
+    for (int gcur = grp0; gcur < grp0 + ngrp;) {
+        const int tbase = gcur & ~(GPCF - 1);            // the ALIGNED tile of the signal that holds group gcur
+        const int gstop = min(tbase + GPCF, grp0 + ngrp);
+        float sreg[3];
+        int lane_t = lane;                               // opaque per tile / per group: nothing derived from the lane id is
+        asm volatile("" : "+v"(lane_t));                 // hoisted out of these loops, held across the transform and spilled
+        canon_fetch(xsig, n, p.col0 + tbase * 16, lane_t, sreg);
+        const CanonTile tile = canon_land(sreg, xrec, p.r2scale_s, p.inv_c, lane_t);
+        for (int gidx = gcur; gidx < gstop; ++gidx) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int tg = p.col0 + gidx * 16;
+            canon_group<KLO, KC>(xrec + (gidx - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg);
+            const int nvalid = min(16, cend - tg);
+            if (p.mode == kModeStack) {
+                f2 piv;
+                const float w = canon_stats<KLO, KC>(own_base, nvalid, tile.inv, lane_o, piv);
+                if constexpr (FUSED) store_partial(part_lds + ((static_cast<int>(ksig) & 1) * kFusedMaxGroups + gidx) * kPartFloats, w, piv.x, piv.y);
+                else store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
+            }
+            f4 o[3];
+            canon_image<KLO, KC>(own_base, ppk_lds, tile.inv, lane_o, o);
+            float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + (tg - p.col0)) * (2 * K)) + lane_o;
+            const int lim = nvalid * (K >> 1);
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (lane_o + 64 * i < lim) {
+                    if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
+                    else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+                }
+            }
+            wave_sync();
+        }
+        gcur = gstop;
+    }
+    if constexpr (FUSED) {
+        const int sl = static_cast<int>(ksig) & 1;
+        unsigned before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(done_a + sl, static_cast<unsigned>(ngrp), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before + static_cast<unsigned>(ngrp) == static_cast<unsigned>(ngroups) * (static_cast<unsigned>(ksig >> 1) + 1u)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int ncols_o = ncols, K_o = K, ng_o = ngroups;
+            asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(ng_o));
+            const float4 st = signal_stats(part_lds + sl * kFusedMaxGroups * kPartFloats, ng_o, 16, ncols_o, K_o, lane_o);
+            if (lane == 0) {
+                fin_stats[static_cast<int>(ksig) & 3] = st;
+                __hip_atomic_store(ready + (static_cast<int>(ksig) & 3), static_cast<unsigned>(ksig) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            wave_sync();
+        }
+    }
+    }
+    chunk = draw();
+    }
+}
+
+}  // namespace hssfsst

@@ -327,7 +327,7 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
 // rounding tie, which are queued for resolve_ties().  `row_disp` points at this lane's frame row (frame j of the
 // group) in the displaced plane.
-template <int NWIN>
+template <int NWIN, int ERRMUL = 1>
 __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* tq, int klo, int K, int kpi, int j,
                                                  float num, float den, f2 V, float R2, f2* own_cell, bool stored)
 {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 #ifdef HSS_NO_TIES                                       // development: cost of the tie path (tools/ab_bench.py)
     if (false) {
 #else
-    if (fr * fr * den < kTieErr2 * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
+    if (fr * fr * den < (kTieErr2 * ERRMUL) * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
 #endif
         constexpr int QI = tie_queue_in(NWIN);          // (constant context: never a call)
         if (stored) {                                   // (wave-uniform) the float32 V is in the own plane: one word
@@ -393,8 +393,10 @@ __device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_b
     }
 }
 
-template <int NWIN>
-__device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_base, int LDF, int* flag, int klo, int K,
+// (`sample(i)` = sample i of the group's first frame as a double: the float tile of fsst_core128_kernel, or the decoded
+//  half-pair records of fsst_canon128.hpp)
+template <int NWIN, class Sample>
+__device__ __forceinline__ void resolve_ties_with(int* tq, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
                                              f2* own_base, int OLD, int cov0,
                                              const double* wtab, const double* twtab, int lane)
 {
@@ -420,7 +422,7 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
             double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
 #pragma unroll 8
             for (int n = 0; n < NWIN; ++n) {                // (unrolled: eight table loads in flight)
-                const double x = static_cast<double>(xg[jf + n]);
+                const double x = sample(jf + n);
                 const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
                 const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
                 const double xw = x * wd.x, xd = x * wd.y;
@@ -436,7 +438,7 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
         double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
 #pragma unroll
         for (int n = lane; n < NWIN; n += 64) {
-            const double x = static_cast<double>(xg[jf + n]);
+            const double x = sample(jf + n);
             const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
             const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
             const double xw = x * wd.x, xd = x * wd.y;
@@ -451,6 +453,14 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
         if (lane == 0) resolve_one<NWIN>(tq, e, n_in, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, kpi, jf, vr, vi, dr, di);
     }
     if (lane == 0) { tq[0] = 0; tq[1] = 0; }
+}
+template <int NWIN>
+__device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                             f2* own_base, int OLD, int cov0,
+                                             const double* wtab, const double* twtab, int lane)
+{
+    resolve_ties_with<NWIN>(tq, [xg](int i) -> double { return static_cast<double>(xg[i]); }, disp_base, LDF, flag, klo, K, own_base, OLD, cov0,
+                       wtab, twtab, lane);
 }
 
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner

@@ -17,6 +17,7 @@
 
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
+#include "fsst_canon128.hpp"
 #include "fsst_team128.hpp"
 #include "fsst_dft.hpp"
 #include "fsst_gather.hpp"
@@ -154,6 +155,10 @@ struct hssfsst_plan {
     double* d_wtab = nullptr;     // float64 {w, dw' in bin units}[nwin], then {cos, sin}(2 pi m / nwin)[nwin]: rounding-tie path
     float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
+    float* d_atab16 = nullptr;    // canonical-band kernels (fsst_canon128.hpp): f16 split A operand [16 taps][64 lanes][8 halves]
+    float canon_inv_c = 0.0f;     // ... 1 / (power-of-two scale of those constants)
+    float canon_r2s = 0.0f;       // ... r2scale x scale^2
+    int canon_slots = 0;          // resident blocks of fsst_canon_kernel<.., false> (0 = not queried yet)
     int nt = 16;                  // taps (per-lane FFT size) of the MFMA kernel: nwin = nt * rq
     float* d_partials = nullptr;  size_t partials_cap = 0;   // floats (kPartFloats per statistics piece)
     unsigned* d_status = nullptr;                            // fused z-score: status word (0 = ok) as the device sees it ...
@@ -378,6 +383,77 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
     return 1;
 }
 
+// Canonical-band kernels (fsst_canon128.hpp): nwin = 128, the band of /root/reference/main.py:153-158 (rows 4..25), STACK /
+// STACK_UNNORM.  kCanonKlo / kCanonK are the one instantiated band; every other band keeps fsst_core128_kernel.
+constexpr int kCanonKlo = 4, kCanonK = 22;
+using CanonBand = hssfsst::CanonCfg<kCanonKlo, kCanonK>;
+
+bool plan_is_canon(const hssfsst_plan* pl)
+{
+    static const bool off = std::getenv("HSSFSST_NO_CANON") != nullptr;             // A/B and cross-check tests
+    return !off && pl->d_atab16 && pl->nwin == 128 && pl->klo == kCanonKlo && pl->K == kCanonK &&
+           (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM);
+}
+
+hssfsst::CanonParams canon_params(const hssfsst_plan* pl, const hssfsst::Core128Params& cp)
+{
+    hssfsst::CanonParams q{};
+    q.x = cp.x; q.out = cp.out; q.partials = cp.partials; q.atab = pl->d_atab16; q.wtab = cp.wtab; q.twtab = cp.twtab;
+    q.r2scale_s = pl->canon_r2s; q.inv_c = pl->canon_inv_c;
+    q.n = cp.n; q.mode = cp.mode; q.nsig = cp.nsig; q.col0 = cp.col0; q.ncols = cp.ncols; q.xstride = cp.xstride; q.reg = cp.reg;
+    q.status = cp.status;
+    return q;
+}
+
+int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
+{
+    constexpr int WPB = 16;
+    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + static_cast<size_t>(WPB) * CanonBand::wave_floats()) * sizeof(float);
+    auto kern = hssfsst::fsst_canon_kernel<kCanonKlo, kCanonK, false>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->canon_slots == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        if (per_cu < 1) per_cu = 1;
+        if (cus < 1) cus = 1;
+        pl->canon_slots = per_cu * cus;
+    }
+    int64_t blocks = nchunks;
+    if (blocks > pl->canon_slots) blocks = pl->canon_slots;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One CU per signal with the z-score in the same launch (see launch_fused128): 1 = launched, 0 = take another path
+int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    constexpr int WPB = 16, GPC = hssfsst::kCanonTileFrames / 16;
+    if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + GPC - 1) / GPC < hssfsst::kFusedMinChunks) return 0;
+    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFusedFloats + static_cast<size_t>(WPB) * CanonBand::wave_floats()) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    auto kern = hssfsst::fsst_canon_kernel<kCanonKlo, kCanonK, true>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->fused_slots == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->fused_slots = (per_cu >= 1 && cus >= 1) ? cus : -1;
+    }
+    if (pl->fused_slots < 1) return 0;
+    const int64_t grid = pl->fused_slots;
+    const int64_t rounds = (batch + grid - 1) / grid;
+    if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
+    if (int rcs = ensure_status(pl)) return rcs;
+    cp.status = pl->d_status;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
+    HIP_TRY(hipGetLastError());
+    return 1;
+}
+
 int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* dout, float* partials, int n, int col0,
                    int ncols, int64_t batch, hipStream_t st, bool try_fused, bool* did_fuse)
 {
@@ -400,6 +476,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     // nwin 128 and 256) get kernels with compile-time stripe tests
     const bool canon = hssfsst::own_s0(pl->klo, rq) == 0 && hssfsst::own_s1(pl->klo, pl->K, rq) == 3;
     *did_fuse = false;
+    const bool canon16 = fast && nt == 16 && rq == 8 && plan_is_canon(pl);
     if (try_fused && fast && nt == 16 && rq == 8 && pl->mode == HSSFSST_MODE_STACK) {
         const int ngroups = (ncols + 15) / 16;
         // two single-launch z-score kernels: full batches of ~2000-sample signals take round 2's one-CU-per-signal kernel
@@ -409,8 +486,9 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         static const bool no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;         // A/B and tests
         static const bool team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr;     // A/B and tests
         int rc = 0;
-        if (!team_only) rc = canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
-        if (rc == 0 && !no_team) {
+        if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
+                             : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
+        if (rc == 0 && !no_team && !canon16) {       // (canon16: until the team kernel shares canon_group)
             rc = canon ? launch_team128<3>(pl, cp, batch, ngroups, st) : launch_team128<-1>(pl, cp, batch, ngroups, st);
             if (rc == 1) { *did_fuse = true; pl->last_zpath = 2; return 0; }
         }
@@ -418,6 +496,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
     }
     if (nt == 16 && rq == 8) {
+        if (canon16) return launch_canon(pl, cp, nchunks, st);
 #ifdef HSS_WPB_CANON
         if (fast && canon) return launch_core128_wpb<16, 8, true, HSS_WPB_CANON, 3>(pl, cp, nchunks, st);
 #endif
@@ -644,6 +723,48 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;
             return fail(HSSFSST_EHIP, "plan_create: A-table upload: %s", hipGetErrorString(e));
         }
+        if (nwin == 128) {
+            // fsst_canon128.hpp: the same constants C_r[n, q] as pairs of halves c1 + c2, scaled by 2^sc into [2^13, 2^14).
+            // Entry (tap n, lane l = (kk, row i), half h): fold term q = 2 kk + (h >> 2), c1 for even h, c2 for odd h
+            // (products x1 c1, x1 c2, x2 c1, x2 c2 against the sample record {x1, x1, x2, x2}).
+            auto comp = [&](int n, int i, int q) -> double {
+                const int gg = i >> 2, sub = i & 3, m = gg;
+                const int r = (sub < 2) ? m : (m ? 8 - m : 4);
+                const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / 8 + static_cast<double>(r) * n / nwin);
+                const double c = std::cos(ang), sn = std::sin(ang);
+                const double sg = (r & 1) ? -0.5 : 0.5;
+                const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
+                return (sub & 1) ? sg * (wv * sn + dv * c) : sg * (wv * c - dv * sn);
+            };
+            double cmax = 0.0;
+            for (int n = 0; n < 16; ++n) for (int i = 0; i < 16; ++i) for (int q = 0; q < 8; ++q) cmax = std::fmax(cmax, std::fabs(comp(n, i, q)));
+            int ex = 0;
+            if (cmax > 0.0 && std::isfinite(cmax)) (void)std::frexp(cmax, &ex);          // cmax = f 2^ex, f in [0.5, 1)
+            const int sc = 14 - ex;                                                       // cmax 2^sc in [2^13, 2^14)
+            const double cs = std::ldexp(1.0, sc);
+            std::vector<unsigned short> ht(static_cast<size_t>(16) * 64 * 8);
+            for (int n = 0; n < 16; ++n)
+                for (int l = 0; l < 64; ++l)
+                    for (int h = 0; h < 8; ++h) {
+                        const int i = l & 15, kk = l >> 4, q = 2 * kk + (h >> 2);
+                        const double v = comp(n, i, q) * cs;
+                        const _Float16 c1 = static_cast<_Float16>(v);
+                        const _Float16 c2 = static_cast<_Float16>(v - static_cast<double>(c1));
+                        const _Float16 pick = (h & 1) ? c2 : c1;
+                        unsigned short bits;
+                        std::memcpy(&bits, &pick, sizeof(bits));
+                        ht[(static_cast<size_t>(n) * 64 + l) * 8 + h] = bits;
+                    }
+            p->canon_inv_c = static_cast<float>(std::ldexp(1.0, -sc));
+            p->canon_r2s = static_cast<float>(static_cast<double>(p->r2scale) * cs * cs);
+            e = hipMalloc(reinterpret_cast<void**>(&p->d_atab16), ht.size() * sizeof(unsigned short));
+            if (e == hipSuccess) e = hipMemcpy(p->d_atab16, ht.data(), ht.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (p->d_atab16) (void)hipFree(p->d_atab16);
+                (void)hipFree(p->d_atab); (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;
+                return fail(HSSFSST_EHIP, "plan_create: f16 A-table upload: %s", hipGetErrorString(e));
+            }
+        }
     }
     *out = p;
     return 0;
@@ -657,6 +778,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_dtab) (void)hipFree(p->d_dtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
+    if (p->d_atab16) (void)hipFree(p->d_atab16);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
