@@ -28,6 +28,7 @@ BYTES_PER_WINDOW = 2000 * 4 + 2000 * 44 * 4      # 8 000 read + 352
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: vector = matrix fp32 peak
 MFMA_FLOP = 2048                                 # one v_mfma_f32_16x16x4_f32: 16 x 16 x 4 x 2
+MFMA_F16_FLOP = 16384                            # one v_mfma_f32_16x16x32_f16: 16 x 16 x 32 x 2
 VALU_FLOP_PER_LANE = 2.0                         # estimate: the VALU mix is ~half packed FMA (4), ~half packed add/mul (2), rest 0-1
 
 
@@ -434,7 +435,11 @@ def main():
         alg = BYTES_PER_WINDOW * B
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         step_gbs = alg / (ms_per_step * 1e-3) / 1e9
-        kname = {1: "fsst_core128_kernel<16, 8, 64, true, 16, 3, true>", 2: "fsst_team128_kernel<3>"}.get(fused, "fsst_core128_kernel<16, 8, 64, true, 16, 3, false>")
+        # (the canonical band runs the kernels of csrc/fsst_canon128.hpp; HSSFSST_NO_CANON=1 -- A/B -- the general ones)
+        if os.environ.get("HSSFSST_NO_CANON"):
+            kname = {1: "fsst_core128_kernel<16, 8, 64, true, 16, 3, true>", 2: "fsst_team128_kernel<3, -1, 0>"}.get(fused, "fsst_core128_kernel<16, 8, 64, true, 16, 3, false>")
+        else:
+            kname = {1: "fsst_canon_kernel<4, 22, true>", 2: "fsst_team128_kernel<3, 4, 22>"}.get(fused, "fsst_canon_kernel<4, 22, false>")
         kdesc = {1: " (transform + z-score in one launch: one CU per signal, tile round-trips through HBM inside the launch)",
                  2: " (transform + z-score in one launch: teams of CUs, features z-scored in registers and written once)"}.get(
                      fused, " (transform; z-score is a second kernel)")
@@ -450,12 +455,19 @@ def main():
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
                 "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / HBM_PEAK_GBS, 5)}
         if prof and "SQ_INSTS_MFMA" in prof and "SQ_INSTS_VALU" in prof and dom_ms > 0:
-            flop = prof["SQ_INSTS_MFMA"] * MFMA_FLOP + prof["SQ_INSTS_VALU"] * 64 * VALU_FLOP_PER_LANE
+            canon = "canon" in kname or "4, 22" in kname
+            flop = (0 if canon else prof["SQ_INSTS_MFMA"] * MFMA_FLOP) + prof["SQ_INSTS_VALU"] * 64 * VALU_FLOP_PER_LANE
             roof["fp32_tflops"] = round(flop / (dom_ms * 1e-3) / 1e12, 2)
             roof["fp32_frac"] = round(flop / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
-            roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
-                                 f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
-                                 f"per launch (profiles/r03_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
+            if canon:
+                roof["mfma_f16_tflops"] = round(prof["SQ_INSTS_MFMA"] * MFMA_F16_FLOP / (dom_ms * 1e-3) / 1e12, 2)
+                roof["fp32_note"] = (f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) per launch, "
+                                     f"peak {FP32_PEAK_TFLOPS} TFLOP/s; besides {int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x32_f16 x {MFMA_F16_FLOP} FLOP "
+                                     "(the window fold with split operands: 4 half products per real one) on the 16-bit matrix pipe (profiles/r03_pmc.json)")
+            else:
+                roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
+                                     f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
+                                     f"per launch (profiles/r03_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
         line = {
             "metric": "PCG windows/sec FSST (1 kHz, 2000-sample)", "value": round(value, 1),
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -466,6 +478,9 @@ def main():
                        "windows_per_gpu": B, "clock_settle_steps": max(args.settle_steps, 0),
                        "untimed_steps_total": untimed,
                        "parallelism": f"window-sharded x{world}, no data-path collective",
+                       "arithmetic": "float32 throughout; the window fold runs on the f16 matrix pipe with split operands "
+                                     "(sample and constant each a pair of halves = 22 bits, fp32 accumulation), every rounding "
+                                     "decision float32 cannot make in float64",
                        "zscore": {1: "same launch (one CU per signal)", 2: "same launch (team kernel)"}.get(fused, "second kernel")},
             "roofline": roof,
         }

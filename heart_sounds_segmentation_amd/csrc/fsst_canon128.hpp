@@ -91,7 +91,7 @@ struct CanonCfg {
     static constexpr int wave_floats() { return 2 * kCanonRecs + 2 * 16 * (LD + LDF) + 4 + kCanonTieWords; }
 };
 
-// Host side of the f16 operand table: entry (tap n, lane l, half h): lane l = (kk, row i); h -> fold term q = 2 kk + (h >> 2),
+// Host side of the f16 operand table: entry (tap n, lane l, half h): lane l = (kk, row i); h -> fold term q = kk + 4 (h >> 2),
 // product h & 3 = {x1 c1, x1 c2, x2 c1, x2 c2} -> the constant's half c1 (h even) or c2 (h odd).  Row i -> (class, re / im) as
 // in the fp32 table of fsst_core128_kernel.  `cs` = 2^sc scales the constants into [2^13, 2^14).
 // (built in hssfsst.hip: canon_build_atab)
@@ -225,7 +225,7 @@ __device__ __forceinline__ void canon_resolve(unsigned* tb, Sample sample, f2* d
             const int jf = act ? __builtin_ctz(hw) : 0;
             hw &= hw - 1u;
             double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 8
+#pragma unroll 2
             for (int n = 0; n < NWIN; ++n) {
                 const double x = sample(jf + n);
                 const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
@@ -245,7 +245,7 @@ __device__ __forceinline__ void canon_resolve(unsigned* tb, Sample sample, f2* d
 // rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
 // xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
 // the group's first output column, for the float64 tie path.
-template <int KLO, int KC>
+template <int KLO, int KC, int TAPB = 4>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
                                             const float* xsig, int n, int tg)
@@ -253,11 +253,12 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
     const int g = lane_o >> 4, j = lane_o & 15;
-    // lane (kk = g, f = j) is row-block kk of the B operand for frame f: records f + tap + 32 kk and + 16 (fold terms 2 kk, 2 kk + 1)
-    unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u2*)(xrec + j + 32 * g)));
+    // lane (kk = g, f = j) is row-block kk of the B operand for frame f: records f + tap + 16 kk and + 64 (fold terms kk, kk + 4:
+    // the 32 lanes of a half-wave then read 32 consecutive records -- every LDS bank once; with terms 2 kk, 2 kk + 1 the two
+    // lane groups of a half-wave were 256 bytes apart, on the same banks)
+    unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u2*)(xrec + j + 16 * g)));
     unsigned aaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u4*)(reinterpret_cast<const u4*>(atab) + lane_o)));
     asm volatile("" : "+v"(xaddr), "+v"(aaddr));
-    const lds_u2* xb = (const lds_u2*)static_cast<size_t>(xaddr);
     const lds_u4* ab = (const lds_u4*)static_cast<size_t>(aaddr);
     int pair = g;
     asm volatile("" : "+v"(pair));
@@ -265,17 +266,23 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     const int rAi = pair, rBi = isg0 ? RQ / 2 : RQ - pair;
 
     f2 za[NT], zb[NT];
-    // (four taps at a time: all 16 are independent, and left alone the scheduler loads every operand first -- 128 registers)
-    static_for<NT / 4>([&](auto GG) {
-        constexpr int g0 = decltype(GG)::value * 4;
-        u4 a[4], b[4];
-        static_for<4>([&](auto I) {
+    // (TAPB taps at a time: all 16 are independent, and left alone the scheduler loads every operand first -- 128 registers)
+    static_for<NT / TAPB>([&](auto GG) {
+        constexpr int g0 = decltype(GG)::value * TAPB;
+        u4 a[TAPB], b[TAPB];
+        static_for<TAPB>([&](auto I) {
             constexpr int n = g0 + decltype(I)::value;
-            const u2 b0 = xb[n], b1 = xb[n + 16];
-            b[n - g0] = u4{b0.x, b0.y, b1.x, b1.y};
+            // records f + n + 16 kk and + 64 in ONE instruction and one register quad (left to itself the compiler pairs
+            // record n with n + 1 -- adjacent addresses -- and then shuffles six registers per two taps)
+            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(b[n - g0]) : "v"(xaddr), "n"(n), "n"(n + 64) : "memory");
             a[n - g0] = ab[n * 64];
         });
-        static_for<4>([&](auto I) {
+        // (the compiler does not count LDS operations issued from inline assembly: wait for them here; its own counts for
+        //  the A operands only become more conservative, LDS returns in order)
+        if constexpr (TAPB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+        else if constexpr (TAPB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]) :: "memory");
+        static_for<TAPB>([&](auto I) {
             constexpr int n = g0 + decltype(I)::value;
             const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[n - g0]), __builtin_bit_cast(h8, b[n - g0]),
                                                                   f4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
@@ -379,8 +386,8 @@ __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, flo
 
 // The group's image [16][2 KC] as this lane's three lane-linear float4s (float4 number lane + 64 i), in feature units.
 // ppk = the wide-store offset table in LDS ([3][64] words, two 16-bit byte offsets each: canon_store_offsets).
-template <int KLO, int KC>
-__device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* ppk, float inv, int lane_o, f4 (&o)[3])
+template <int KLO, int KC, class Sink>
+__device__ __forceinline__ void canon_image_to(const f2* own_base, const unsigned* ppk, float inv, int lane_o, Sink sink)
 {
     unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
     asm volatile("" : "+s"(obase));                      // ONE scalar base: each cell is then "offset + base", no second add
@@ -391,8 +398,13 @@ __device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* 
         const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
         const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
         const f2 lo = f2{q0[0], q0[2]} * sc, hi = f2{q1[0], q1[2]} * sc;
-        o[i] = f4{lo.x, lo.y, hi.x, hi.y};
+        sink(i, f4{lo.x, lo.y, hi.x, hi.y});
     }
+}
+template <int KLO, int KC>
+__device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* ppk, float inv, int lane_o, f4 (&o)[3])
+{
+    canon_image_to<KLO, KC>(own_base, ppk, inv, lane_o, [&](int i, f4 v) { o[i] = v; });
 }
 
 // Byte offsets, inside the own plane, of the two (re, re) / (im, im) pairs of float4 number f = lane + 64 i of a group's
@@ -602,19 +614,22 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
+    const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     for (int gcur = grp0; gcur < grp0 + ngrp;) {
-        const int tbase = gcur & ~(GPCF - 1);            // the ALIGNED tile of the signal that holds group gcur
-        const int gstop = min(tbase + GPCF, grp0 + ngrp);
+        // the ALIGNED tile of the signal that holds group gcur: aligned in absolute columns, so that a column-range exec
+        // stages the very tiles -- and scales -- of the whole-signal transform
+        const int tbase = (gcur + cg0) & ~(GPCF - 1);    // absolute group index of the tile's first group
+        const int gstop = min(tbase + GPCF - cg0, grp0 + ngrp);
         float sreg[3];
         int lane_t = lane;                               // opaque per tile / per group: nothing derived from the lane id is
         asm volatile("" : "+v"(lane_t));                 // hoisted out of these loops, held across the transform and spilled
-        canon_fetch(xsig, n, p.col0 + tbase * 16, lane_t, sreg);
+        canon_fetch(xsig, n, tbase * 16, lane_t, sreg);
         const CanonTile tile = canon_land(sreg, xrec, p.r2scale_s, p.inv_c, lane_t);
         for (int gidx = gcur; gidx < gstop; ++gidx) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int tg = p.col0 + gidx * 16;
-            canon_group<KLO, KC>(xrec + (gidx - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg);
+            canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg);
             const int nvalid = min(16, cend - tg);
             if (p.mode == kModeStack) {
                 f2 piv;

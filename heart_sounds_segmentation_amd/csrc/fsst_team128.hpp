@@ -30,6 +30,7 @@
 // reports through the plan's status word instead of hanging.
 #pragma once
 #include "fsst_mfma128.hpp"
+#include "fsst_canon128.hpp"
 
 namespace hssfsst {
 
@@ -38,6 +39,7 @@ constexpr int kTeamGpc = 4;                  // groups per chunk = one 64-frame 
 constexpr int kTeamMailSlots = 64;           // mailbox slots per team (signal ordinal mod this)
 constexpr int kTeamWindow = 31;              // a CU starts no chunk this many signals ahead of its oldest unresolved signal
 constexpr int kTeamMaxChunks = 64;           // chunks per signal the mailbox layout allows (signals up to 4096 frames)
+constexpr int kTeamPark = 2;                 // canonical-band instantiation: groups of the held chunk that wait in LDS, not in registers
 constexpr int kTeamPf = 2;                   // mailbox blocks per lane requested in one go (16 kTeamPf chunks = 2048 frames)
 constexpr int kTeamCtlFloats = 16 + 64 + 192;    // [0] work counter, [1] a wait gave up, [8..15] oldest unresolved signal per
                                                  // wave, [16..79] column classes, [80..271] wide-store offsets
@@ -53,6 +55,7 @@ struct Team128Params {
     unsigned long long* mail;   // [teams][kTeamMailSlots][nchunks][8] tagged words {tag << 32 | half of a double}
     unsigned* status;     // device status word (0 = ok)
     float r2scale;
+    float inv_c;          // canonical-band instantiation: 1 / (scale of the f16 constants)
     int n, klo, K, nsig, col0, ncols;
     long long xstride;
     int team;             // CUs per team (power of two, <= 32, <= nchunks)
@@ -61,22 +64,30 @@ struct Team128Params {
     int nchunks;          // chunks per signal
     unsigned seq;         // launch sequence number of the plan (upper half of the mailbox tags)
     unsigned spin_ticks;  // bound of a wait in 100 MHz ticks
+    unsigned* arrive;     // arrival counter of the plan (monotone over launches)
+    unsigned arrive_base; // its value before this launch: block identity = arrival number - arrive_base
+    int static_ids;       // development: block identity = blockIdx (teams inside one XCD, but no progress guarantee)
     unsigned long long* probe;   // development (HSS_TEAM_PROBE): per-phase shader-clock totals over all waves
 };
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
-template <int S1C>
+// (KLO, KC) >= 0: the band is that compile-time constant and a chunk's transform is canon_group / canon_stats / canon_image
+// of fsst_canon128.hpp (p.atab = the f16 operand table, p.r2scale = its scaled r2scale, p.inv_c its constant scale) -- the
+// same arithmetic as fsst_canon_kernel, hence bit-identical features on every z-score path.
+template <int S1C, int KLO = -1, int KC = 0>
 __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team128Params p)
 {
+    constexpr bool CANON = KLO >= 0;
+    using CC = CanonCfg<(CANON ? KLO : 4), (CANON ? KC : 22)>;
     constexpr int NT = 16, RQ = 8, NWIN = 128, KST = 2, FPW = 16 * kTeamGpc, WPB = kTeamWaves;
-    constexpr int ATAB = core128_atab_floats(RQ, NT);
+    constexpr int ATAB = CANON ? kCanonAtabFloats : core128_atab_floats(RQ, NT);
     constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
     using avec = float __attribute__((ext_vector_type(KST)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = p.K, klo = p.klo, n = p.n;
-    const int LDF = plane_ldf(K);
-    const int OLD = own_ld(klo, K, RQ);
+    const int K = CANON ? KC : p.K, klo = CANON ? KLO : p.klo, n = p.n;
+    const int LDF = CANON ? CC::LDF : plane_ldf(K);
+    const int OLD = CANON ? CC::LD : own_ld(klo, K, RQ);
     const int s0 = (S1C >= 0) ? 0 : own_s0(klo, RQ), s1 = (S1C >= 0) ? S1C : own_s1(klo, K, RQ);
 
     const int lane = threadIdx.x & 63;
@@ -87,22 +98,41 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     int* pend = reinterpret_cast<int*>(smem + ATAB) + 8;                     // [kTeamWaves]
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64]
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // [3][64]
-    float* wbase = smem + ATAB + kTeamCtlFloats + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
+    float* wbase = smem + ATAB + kTeamCtlFloats + wv * (CANON ? CC::wave_floats() : wave_lds_floats(FPW, klo, K, RQ, NT));
     float* xs = wbase;
-    f2* own_base = reinterpret_cast<f2*>(wbase + XS);
+    // CANON: the held chunk's last kTeamPark groups (three float4 per lane and group) wait in LDS instead of registers -- 3 kB
+    // per wave and group that this 8-wave kernel has to spare; the registers are what the allocator was short of (it spilled
+    // them to scratch)
+    f4* park = reinterpret_cast<f4*>(smem + ATAB + kTeamCtlFloats + WPB * (CANON ? CC::wave_floats() : 0)) + wv * 3 * 64 * kTeamPark;
+    f2* own_base = reinterpret_cast<f2*>(wbase + (CANON ? 2 * kCanonRecs : XS));
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
     int* tq = flag + 4;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) {
-        const int ks = i % KST, l = (i / KST) & 63, pt = i / (KST * 64);
-        atab[i] = p.atab[(pt * KST + ks) * 64 + l];
+        if constexpr (CANON) {
+            atab[i] = p.atab[i];
+        } else {
+            const int ks = i % KST, l = (i / KST) & 63, pt = i / (KST * 64);
+            atab[i] = p.atab[(pt * KST + ks) * 64 + l];
+        }
     }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
+    if constexpr (CANON) {
+        if (lane < 4) flag[lane] = 0;
+        if (lane < kCanonTieWords) tq[lane] = 0;
+    } else if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
     if (threadIdx.x < 8) next_q[threadIdx.x] = 0;
     if (threadIdx.x >= 8 && threadIdx.x < 16) next_q[threadIdx.x] = 0x7fffffff;      // pend[]: nothing unresolved
+    // Block identity = ARRIVAL number, not blockIdx: the blocks that are running always hold the identities 0 .. R - 1, so
+    // every team below R / T is complete whatever share of the chip this launch was given (another process's kernels may
+    // hold the rest -- DataLoader workers, /root/reference/main.py:202-218), and a complete team depends on nobody else:
+    // it finishes, frees its CUs, the next blocks arrive.  With blockIdx as identity two processes could each hold half of
+    // every team and wait for the other half until the time limit.
+    if (threadIdx.x == 2)
+        next_q[2] = p.static_ids ? static_cast<int>(blockIdx.x)
+                                 : static_cast<int>(__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base);
     if (wv == 0) {
         unsigned cls = 0u;                               // bit 2i / 2i+1: the first / second pair of float4 i is imaginary
 #pragma unroll
@@ -112,20 +142,25 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
             cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
         }
         cls_lds[lane] = cls;
-        const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
+        if constexpr (CANON) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            ppk_lds[i * 64 + lane] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
+            for (int i = 0; i < 3; ++i) ppk_lds[i * 64 + lane] = canon_store_offsets<(CANON ? KLO : 4), (CANON ? KC : 22)>(lane + 64 * i);
+        } else {
+            const int* ptab = reinterpret_cast<const int*>(p.atab + ATAB);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                ppk_lds[i * 64 + lane] = static_cast<unsigned>(ptab[i * 64 + lane]) | (static_cast<unsigned>(ptab[(3 + i) * 64 + lane]) << 16);
+        }
     }
     __syncthreads();
 
-    // ---- team geometry (wave-uniform).  Blocks are dealt to the XCDs round-robin (block b runs on XCD b % 8), so the
-    //      T blocks {b : b % 8 == x, (b / 8) / T == h} are T CUs of ONE XCD: their mailbox lives in that XCD's L2.
-    //      (Only performance depends on that placement: the mailbox protocol is agent-scope.)
+    // ---- team geometry (wave-uniform): T consecutive identities form a team.  (static_ids: blocks are dealt to the XCDs
+    //      round-robin, block b on XCD b % 8, and the T blocks {b : b % 8 == x, (b / 8) / T == h} are T CUs of ONE XCD.)
     const int T = p.team, cpc = p.cpc, NC = p.nchunks;
-    const int xcd = static_cast<int>(blockIdx.x) & 7, cu_slot = static_cast<int>(blockIdx.x) >> 3;
-    const int member = cu_slot & (T - 1);
-    const int team = xcd + 8 * (cu_slot / T);
+    const int virt = __builtin_amdgcn_readfirstlane(next_q[2]);
+    const int xcd = virt & 7, cu_slot = virt >> 3;
+    const int member = p.static_ids ? (cu_slot & (T - 1)) : (virt & (T - 1));
+    const int team = p.static_ids ? xcd + 8 * (cu_slot / T) : virt / T;
     const int nteams = static_cast<int>(gridDim.x) / T;
     const int nk = (p.nsig > team) ? (p.nsig - team + nteams - 1) / nteams : 0;      // signals of this team
     const int nwork = nk * cpc;
@@ -165,6 +200,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     int ko_prev = 0, grp0_prev = 0, ngrp_prev = 0;
     long long b_prev = 0;
     f16v prev[3], cur[3];
+    f4 prevq[3][kTeamGpc], curq[3][kTeamGpc];            // CANON: the same sets as float4s (the group index is a switch, no indexed moves)
 
     // ---- draw: the next chunk of this CU's list (-> it_valid, ko, c) and its samples on their way into registers.
     //      The wave first registers a lower bound of the oldest signal it will hold unresolved -- `lower_hint`, or the
@@ -177,6 +213,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     bool it_valid = false;                               // the LANDED chunk: its tile is in xs, next to be transformed
     int ko = 0, c = 0;
     float R2 = 0.0f;                                     // error-bound scale of the tile in xs (see "Rounding ties")
+    CanonTile tile{};                                    // CANON: the landed tile's scales
     auto draw = [&](int lower_hint) {
         int qi = 0;
         if (lane == 0) {
@@ -214,6 +251,11 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         if (!it_valid) return;
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
+        if constexpr (CANON) {
+            static_assert(!CANON || SREG == 3, "canon_land takes the aligned tile as three samples per lane");
+            tile = canon_land(sreg, reinterpret_cast<u2*>(xs), p.r2scale, p.inv_c, lane_o);
+            return;
+        }
         float e2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < SREG; ++k) {
@@ -280,6 +322,14 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
 #pragma unroll
             for (int r = 0; r < 2 * kTeamPf; ++r) pf[r] = 0ull;
             const bool pf_on = have_prev && NC <= 16 * kTeamPf;
+            if constexpr (CANON) {
+                // the set about to be filled carries nothing over from the previous chunk: say so (an empty statement that
+                // "defines" the registers), otherwise 48 registers stay live around the loop for a chunk of fewer than 4 groups
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int g = 0; g < kTeamGpc; ++g) asm volatile("" : "=v"(curq[i][g]));
+            }
             for (int grp = 0; grp < ngrp; ++grp) {
                 if (pf_on && grp == ngrp - 1) {
 #pragma unroll
@@ -290,6 +340,27 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                     }
                 }
                 const int tg = t0 + grp * 16;
+                if constexpr (CANON) {
+                    canon_group<KLO, KC, 2>(reinterpret_cast<const u2*>(xs) + grp * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab,
+                                         tile, tiny, lane_o, p.x + b * p.xstride, n, tg);
+                    const int nvalid = min(16, cend - tg);
+                    f2 piv;
+                    const float w = canon_stats<KLO, KC>(own_base, nvalid, tile.inv, lane_o, piv);
+                    const float wo = __shfl_xor(w, 16);
+                    const int q = lane_o >> 4;
+                    const float s1f = (q & 1) ? wo : w, s2f = (q & 1) ? w : wo;
+                    const float pf32 = (q & 2) ? piv.y : piv.x;
+                    const double cnt = static_cast<double>(nvalid) * static_cast<double>(K);
+                    bsum += piece_moment(q, static_cast<double>(s1f), static_cast<double>(s2f), static_cast<double>(pf32), cnt);
+                    // the group index is wave-uniform: a four-way branch around the 12 LDS reads of the image, each arm
+                    // writing its own float4 registers (no M0-indexed moves, no 16-register tuples to keep aligned)
+                    static_for<kTeamGpc>([&](auto G) {
+                        constexpr int gq = decltype(G)::value;
+                        if (grp == gq) canon_image_to<KLO, KC>(own_base, ppk_lds, tile.inv, lane_o, [&](int i, f4 v) { curq[i][gq] = v; });
+                    });
+                    wave_sync();
+                    continue;
+                }
                 unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + j + NT * g)));
                 asm volatile("" : "+v"(xaddr));
                 const lds_float* xb = (const lds_float*)static_cast<size_t>(xaddr);
@@ -509,8 +580,11 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (lane_r + 64 * i < lim) {
-                        const f2 lo = zs(f2{prev[i][4 * g], prev[i][4 * g + 1]}, ms[i][0]);
-                        const f2 hi = zs(f2{prev[i][4 * g + 2], prev[i][4 * g + 3]}, ms[i][1]);
+                        f4 pv;
+                        if constexpr (CANON) pv = (g >= kTeamGpc - kTeamPark) ? park[((g - (kTeamGpc - kTeamPark)) * 3 + i) * 64 + lane_r] : prevq[i][g];
+                        else pv = f4{prev[i][4 * g], prev[i][4 * g + 1], prev[i][4 * g + 2], prev[i][4 * g + 3]};
+                        const f2 lo = zs(f2{pv.x, pv.y}, ms[i][0]);
+                        const f2 hi = zs(f2{pv.z, pv.w}, ms[i][1]);
 #if defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 1        // development: plain stores
                         *reinterpret_cast<f4*>(d4 + g * per + 64 * i) = f4{lo.x, lo.y, hi.x, hi.y};
 #elif defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 2      // development: the arithmetic without the stores
@@ -524,13 +598,22 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 }
             }
 #else
-            if (lane_r == 0 && prev[0][0] == 123.456f) p.out[0] = ms[0][0].x + ms[1][1].y;
+            if (lane_r == 0 && (CANON ? prevq[0][0].x : prev[0][0]) == 123.456f) p.out[0] = ms[0][0].x + ms[1][1].y;
 #endif
             have_prev = false;
             PROBE(5);
         }
         if (xf) {
-            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            if constexpr (CANON) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int g = 0; g < kTeamGpc - kTeamPark; ++g) prevq[i][g] = curq[i][g];
+#pragma unroll
+                    for (int g = kTeamGpc - kTeamPark; g < kTeamGpc; ++g) park[((g - (kTeamGpc - kTeamPark)) * 3 + i) * 64 + lane_r] = curq[i][g];
+                }
+                wave_sync();
+            } else { prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2]; }
             have_prev = true; ko_prev = ko_cur; grp0_prev = grp0; ngrp_prev = ngrp; b_prev = b;
         } else if (!it_valid) {
             break;

@@ -165,6 +165,7 @@ struct hssfsst_plan {
     volatile unsigned* h_status = nullptr;                   // ... and the same word in pinned host memory: read without a sync
     unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][chunks][8] (8-byte words)
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
+    unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: arrival counter and its value after the launches so far
     int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
     int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
     int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
@@ -314,16 +315,19 @@ int ensure_status(hssfsst_plan* pl)
 
 // Team kernel launch (fsst_team128.hpp): nwin = 128, STACK, wide-store epilogue.  Returns 1 when it launched, 0 when
 // this exec should take another path, < 0 on error.
-template <int S1C>
+template <int S1C, int KLO = -1, int KC = 0>
 int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
 {
     using namespace hssfsst;
+    constexpr bool CANON = KLO >= 0;
     const int NC = (ngroups + kTeamGpc - 1) / kTeamGpc;
     if (NC < 1 || NC > kTeamMaxChunks) return 0;
-    const size_t lds = (core128_atab_floats(8, 16) + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
-                        wave_lds_floats(16 * kTeamGpc, pl->klo, pl->K, 8, 16)) * sizeof(float);
+    const size_t lds = CANON ? (kCanonAtabFloats + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
+                                (CanonCfg<(CANON ? KLO : 4), (CANON ? KC : 22)>::wave_floats() + 3 * 64 * 4 * kTeamPark)) * sizeof(float)
+                             : (core128_atab_floats(8, 16) + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
+                                wave_lds_floats(16 * kTeamGpc, pl->klo, pl->K, 8, 16)) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    auto kern = fsst_team128_kernel<S1C>;
+    auto kern = fsst_team128_kernel<S1C, KLO, KC>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->team_cus == 0) {
@@ -359,9 +363,18 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
     Team128Params tp{};
     tp.x = cp.x; tp.out = cp.out; tp.atab = cp.atab; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
     tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale = cp.r2scale;
+    if (CANON) { tp.atab = pl->d_atab16; tp.r2scale = pl->canon_r2s; tp.inv_c = pl->canon_inv_c; }
     tp.n = cp.n; tp.klo = cp.klo; tp.K = cp.K; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
     tp.team = T; tp.cpc = cpc; tp.cpc_shift = cpc_shift; tp.nchunks = NC; tp.seq = pl->team_seq;
     tp.spin_ticks = 200u * 1000u * 1000u;                // 2 s of the 100 MHz counter
+    if (!pl->d_arrive) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, sizeof(unsigned), st));
+        pl->arrive_total = 0;
+    }
+    static const bool static_ids = std::getenv("HSSFSST_TEAM_STATIC") != nullptr;  // A/B: teams inside one XCD, no progress guarantee
+    tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total; tp.static_ids = static_ids ? 1 : 0;
+    pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
 #ifdef HSS_TEAM_PROBE
     static unsigned long long* d_probe = nullptr;
     static int probe_runs = 0;
@@ -476,7 +489,9 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     // nwin 128 and 256) get kernels with compile-time stripe tests
     const bool canon = hssfsst::own_s0(pl->klo, rq) == 0 && hssfsst::own_s1(pl->klo, pl->K, rq) == 3;
     *did_fuse = false;
-    const bool canon16 = fast && nt == 16 && rq == 8 && plan_is_canon(pl);
+    // (tiles are aligned in absolute columns: a column range must start on a 16-frame group boundary -- on a 64-frame tile
+    //  boundary for the team kernel, whose chunks are whole tiles; other ranges take fsst_core128_kernel)
+    const bool canon16 = fast && nt == 16 && rq == 8 && plan_is_canon(pl) && (col0 & 15) == 0;
     if (try_fused && fast && nt == 16 && rq == 8 && pl->mode == HSSFSST_MODE_STACK) {
         const int ngroups = (ncols + 15) / 16;
         // two single-launch z-score kernels: full batches of ~2000-sample signals take round 2's one-CU-per-signal kernel
@@ -488,8 +503,9 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         int rc = 0;
         if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
                              : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
-        if (rc == 0 && !no_team && !canon16) {       // (canon16: until the team kernel shares canon_group)
-            rc = canon ? launch_team128<3>(pl, cp, batch, ngroups, st) : launch_team128<-1>(pl, cp, batch, ngroups, st);
+        if (rc == 0 && !no_team && !(canon16 && (col0 & 63) != 0)) {
+            rc = canon16 ? launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st)
+                 : canon ? launch_team128<3>(pl, cp, batch, ngroups, st) : launch_team128<-1>(pl, cp, batch, ngroups, st);
             if (rc == 1) { *did_fuse = true; pl->last_zpath = 2; return 0; }
         }
         if (rc < 0) return rc;
@@ -725,7 +741,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
         }
         if (nwin == 128) {
             // fsst_canon128.hpp: the same constants C_r[n, q] as pairs of halves c1 + c2, scaled by 2^sc into [2^13, 2^14).
-            // Entry (tap n, lane l = (kk, row i), half h): fold term q = 2 kk + (h >> 2), c1 for even h, c2 for odd h
+            // Entry (tap n, lane l = (kk, row i), half h): fold term q = kk + 4 (h >> 2), c1 for even h, c2 for odd h
             // (products x1 c1, x1 c2, x2 c1, x2 c2 against the sample record {x1, x1, x2, x2}).
             auto comp = [&](int n, int i, int q) -> double {
                 const int gg = i >> 2, sub = i & 3, m = gg;
@@ -746,7 +762,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             for (int n = 0; n < 16; ++n)
                 for (int l = 0; l < 64; ++l)
                     for (int h = 0; h < 8; ++h) {
-                        const int i = l & 15, kk = l >> 4, q = 2 * kk + (h >> 2);
+                        const int i = l & 15, kk = l >> 4, q = kk + 4 * (h >> 2);
                         const double v = comp(n, i, q) * cs;
                         const _Float16 c1 = static_cast<_Float16>(v);
                         const _Float16 c2 = static_cast<_Float16>(v - static_cast<double>(c1));
@@ -782,6 +798,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
+    if (p->d_arrive) (void)hipFree(p->d_arrive);
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
