@@ -10,7 +10,7 @@
 //    f16 range), and the four products x1 c1, x1 c2, x2 c1, x2 c2 of the 8 fold terms are exactly the K = 32 of ONE
 //    v_mfma_f32_16x16x32_f16 per tap (fp32 accumulation; the products of two halves are exact in it).  Error per term
 //    <= 2^-22 |x c| -- the same order as the fp32 FMA chain it replaces -- and every rounding decision that float32
-//    cannot make is still made in float64 from the signal's own float32 samples (canon_resolve reads them from HBM).  The tile of a group is the ALIGNED
+//    cannot make is still made in float64 from the signal's own float32 samples (resolve_bitmap reads them from HBM).  The tile of a group is the ALIGNED
 //    64-frame window of its signal whatever kernel or chunking processes it, so the power-of-two scale -- and with it every
 //    bit of the result -- does not depend on the path (two-launch, one CU per signal, team);
 //  * the band is a constant: the own plane covers rows 4 floor(KLO / 4) .. only (24 instead of 32 columns: that is what
@@ -34,14 +34,7 @@ constexpr int kCanonTileFrames = 64;                     // frames per aligned t
 constexpr int kCanonRecs = 192;                          // sample records per tile: 64 + 127, rounded up
 constexpr int kCanonAtabFloats = 16 * 64 * 4;            // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
 constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
-// Rounding ties of this kernel: no queues.  A cell whose float32 coordinate is too close to a half-integer sets ONE BIT of a
-// per-group bitmap in LDS -- bit 16 (k' & 1) + frame of word k' >> 1, k' = 0..63 -- so the number of undecided cells of a
-// group is not limited by anything (the queues of fsst_core128_kernel hold 240 + 24 and fall back to float32 beyond that:
-// tonal and offset-dominated inputs under low-sidelobe windows overflowed them, profiles/r02_adversarial_parity.txt class
-// iii), and the bitmap is a sixth of their size.  Resolution (canon_resolve): up to kTieCoop cells one by one with the whole
-// wave on one float64 DFT; more than that, lane l takes source k' = l and walks its 16 frame bits.  The float32 V of a cell
-// inside the stored cover is read back from -- and cleared in -- its own column; for a cell outside it V is the float64
-// DFT's own result (rounded once), so nothing has to be carried along.
+// (rounding ties: the bitmap of fsst_mfma128.hpp, "Rounding ties"; the float64 path reads the signal's own samples)
 constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
 
 template <int KLO, int KC>
@@ -154,93 +147,6 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
     move_source<NWIN, true>(row_disp, flag, KLO, KC, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
 }
 
-// One undecided cell (k', frame jf) with its float64 spectrum values V = (vr, vi), Vd' = (dr, di) (true units, no sign):
-// the float64 coordinate rounded half away from zero, then the move.  plane_scale = 1 / tile.inv.
-template <int KLO, int KC>
-__device__ __forceinline__ void canon_resolve_one(f2* disp_base, int* flag, f2* own_base, int kpi, int jf,
-                                                  double vr, double vi, double dr, double di, double plane_scale)
-{
-    using C = CanonCfg<KLO, KC>;
-    constexpr int NWIN = 128;
-    const double den = vr * vr + vi * vi;
-    double shift = (dr * vi - di * vr) / den;
-    if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
-    const double a = static_cast<double>(kpi) + shift;
-    const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
-    const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
-    const int h = kpi >> 2;
-    if (h >= C::H0 && h <= C::H1) {                      // inside the stored cover: the float32 V sits in its own column
-        f2* cell = own_base + jf * C::LD + (kpi - C::COV0);
-        const f2 V = *cell;
-        move_source<NWIN, true>(disp_base + jf * C::LDF, flag, KLO, KC, kpi, row, V, cell, true);
-    } else {
-        const double sg = (kpi & 1) ? -plane_scale : plane_scale;                   // the plane holds (-1)^k' V[k'], scaled
-        const f2 V = {static_cast<float>(vr * sg), static_cast<float>(vi * sg)};
-        move_source<NWIN, true>(disp_base + jf * C::LDF, flag, KLO, KC, kpi, row, V, nullptr, false);
-    }
-}
-
-template <int KLO, int KC, class Sample>
-__device__ __forceinline__ void canon_resolve(unsigned* tb, Sample sample, f2* disp_base, int* flag, f2* own_base,
-                                              const double* wtab, const double* twtab, double plane_scale, int lane)
-{
-    constexpr int NWIN = 128;
-    unsigned w = (lane < 32) ? tb[lane] : 0u;
-    int total = __popc(w);
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) total += __shfl_xor(total, off);
-    total = __builtin_amdgcn_readfirstlane(total);
-    if (total <= kTieCoop) {
-        // few cells: one by one, all lanes on one cell (two taps per lane, float64 butterfly sum)
-        for (int it = 0; it < total; ++it) {
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(w != 0u);
-            const int l0 = __builtin_ctzll(mask);
-            const unsigned ww = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), l0));
-            const int bit = __builtin_ctz(ww);
-            if (lane == l0) w &= w - 1u;
-            const int kpi = 2 * l0 + (bit >> 4), jf = bit & 15;
-            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll
-            for (int n = lane; n < NWIN; n += 64) {
-                const double x = sample(jf + n);
-                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-                const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
-                const double xw = x * wd.x, xd = x * wd.y;
-                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
-            }
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
-                dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
-            }
-            if (lane == 0) canon_resolve_one<KLO, KC>(disp_base, flag, own_base, kpi, jf, vr, vi, dr, di, plane_scale);
-        }
-    } else {
-        // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = l and walks
-        // the frames whose bit is set -- at most 16 rounds, every round a full float64 DFT per lane
-        unsigned hw = (tb[lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
-        while (__builtin_amdgcn_ballot_w64(hw != 0u) != 0ull) {
-            const bool act = hw != 0u;
-            const int jf = act ? __builtin_ctz(hw) : 0;
-            hw &= hw - 1u;
-            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 2
-            for (int n = 0; n < NWIN; ++n) {
-                const double x = sample(jf + n);
-                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-                const double2 cs = reinterpret_cast<const double2*>(twtab)[(lane * n) & (NWIN - 1)];
-                const double xw = x * wd.x, xd = x * wd.y;
-                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
-            }
-            if (act) canon_resolve_one<KLO, KC>(disp_base, flag, own_base, lane, jf, vr, vi, dr, di, plane_scale);
-        }
-    }
-    if (lane < 32) tb[lane] = 0u;
-    if (lane == 0) flag[1] = 0;
-}
-
 // The group's transform up to and including the scatter: on return the own plane [16][LD] holds the group's synchrosqueezed
 // rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
 // xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
@@ -327,10 +233,10 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
         // 1e-5 bins from a half-integer needs all 24
-        canon_resolve<KLO, KC>(reinterpret_cast<unsigned*>(tq), [&](int i) -> double {
+        resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), [&](int i) -> double {
             const int gi = tg + i - NWIN / 2;
             return (gi >= 0 && gi < n) ? static_cast<double>(xsig[gi]) : 0.0;
-        }, disp_base, flag, own_base, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        }, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
     }

@@ -261,15 +261,15 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // HBM, a float64 butterfly sum) and rounds the float64 coordinate.  Cells below 1e-6 R are left to float32: they
 // cannot change a feature by 1e-4 of the largest feature wherever they land.  Large cells have tau ~ 1e-6 and are
 // practically never queued; the queue holds the small far-moving cells that float32 cannot place.
-// Two queues per wave and 16-frame group (overflow falls back to float32 rounding): cells whose float32 V sits in the
-// own plane (sources inside the stored cover: the rows next to the band, the cells that matter most) take 16 bits,
-// bin | frame << 9, and their V is read back -- and cleared -- there; sources outside the cover carry their V along
-// (a group of a longer window has proportionally more uncertain cells on a tonal input: 1008 for nwin 512, where LDS is not what
-//  limits the waves; 240 for 128 and 256)
-__host__ __device__ constexpr int tie_queue_in(int nwin) { return nwin >= 512 ? 1008 : 240; }  // [4 ..): 16-bit entries, bin | frame << 9
-constexpr int kTieQueueOut = 24;             // behind them: {bin | frame << 16, V.re, V.im}
-constexpr int kTieCoop = 6;                  // up to this many queued cells the wave resolves them one by one, all lanes on one cell
-__host__ __device__ constexpr int tie_words(int nwin) { return 4 + tie_queue_in(nwin) / 2 + 3 * kTieQueueOut; }   // [0] in-cover count, [1] out-of-cover count
+// No queues (rounds 1-2 queued such cells, 240 + 24 per group, and fell back to float32 beyond that: tonal and offset-
+// dominated inputs under low-sidelobe windows overflowed them -- profiles/r02_adversarial_parity.txt class iii): an undecided
+// cell sets ONE BIT of a per-group bitmap in LDS, bit 16 (k' & 1) + frame of word k' >> 1, k' = 0 .. nwin/2 - 1, so their number
+// is not limited by anything and the bitmap is a sixth of the queues' size.  Resolution (resolve_bitmap): per set of 64
+// sources, up to kTieCoop cells one by one with the whole wave on one float64 DFT; more than that, lane l takes source
+// k' = l of the set and walks its 16 frame bits.  The float32 V of a cell inside the stored cover of the own plane is read
+// back from -- and cleared in -- its own column; for a cell outside it V is the float64 DFT's own result, rounded once.
+constexpr int kTieCoop = 6;                  // up to this many undecided cells of a 64-source set the wave resolves one by one
+__host__ __device__ constexpr int tie_words(int nwin) { return nwin / 4; }     // the bitmap (flag[1] = "some bit is set")
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
 constexpr float kTieErr2 = 1.0e-12f;         // (1e-6)^2: tau^2 = kTieErr2 (1 + |shift|)^2 R^2 / |V|^2  (4e-7 left 2 of 1000
                                              // random configurations 1.4-1.8x over the gate: tools/fuzz_parity.py 1000 3)
@@ -344,37 +344,24 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 #else
     if (fr * fr * den < (kTieErr2 * ERRMUL) * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
 #endif
-        constexpr int QI = tie_queue_in(NWIN);          // (constant context: never a call)
-        if (stored) {                                   // (wave-uniform) the float32 V is in the own plane: one word
-            const int slot = __hip_atomic_fetch_add(tq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < QI) {
-                reinterpret_cast<unsigned short*>(tq + 4)[slot] = static_cast<unsigned short>(kpi | (j << 9));
-                return;
-            }
-        } else {
-            const int slot = __hip_atomic_fetch_add(tq + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < kTieQueueOut) {
-                int* q = tq + 4 + QI / 2 + 3 * slot;
-                q[0] = kpi | (j << 16);
-                q[1] = __float_as_int(V.x);
-                q[2] = __float_as_int(V.y);
-                return;
-            }
-        }
+        __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(tq) + (kpi >> 1), 1u << (((kpi & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        flag[1] = 1;
+        return;
     }
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
     move_source<NWIN, true>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
 }
 
-// The whole wave, after the group's spectra: every queued cell's bin of V and Vd' by a float64 DFT of its frame
-// (xg = the group's first frame in the LDS tile; wtab[n] = {w, dw'}[n], twtab[m] = {cos, sin}(2 pi m / nwin), float64),
-// the float64 coordinate k' - Im(Vd'/V) rounded half away from zero, then the move of the float32 V: read back from --
-// and cleared in -- the source's own column (in-cover queue: columns [cov0, ..) of the own plane, leading dimension
-// OLD), or carried by the entry (out-of-cover queue: no own cell, none in the band).  Entry e of the combined list:
-// e < n_in -> in-cover queue, else out-of-cover queue.
+// The whole wave, after the group's spectra: every undecided cell's bin of V and Vd' by a float64 DFT of its frame
+// (sample(i) = sample i of the group's first frame as a double: the float32 signal itself; wtab[n] = {w, dw'}[n],
+// twtab[m] = {cos, sin}(2 pi m / nwin), float64), the float64 coordinate k' - Im(Vd'/V) rounded half away from zero, then the
+// move.  [cov0, cov1) = the sources whose float32 V sits in the own plane (leading dimension OLD): it is read back from --
+// and cleared in -- its own column; a source outside the cover has no own cell and none in the band: its V is the float64
+// DFT's, times the plane's sign (-1)^k' (even nwin: the modified-STFT phase) and `plane_scale` (1 unless the plane holds
+// scaled values, fsst_canon128.hpp).
 template <int NWIN>
-__device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_base, int LDF, int* flag, int klo, int K,
-                                            f2* own_base, int OLD, int cov0, int kpi, int jf, double vr, double vi, double dr, double di)
+__device__ __forceinline__ void resolve_one(f2* disp_base, int LDF, int* flag, int klo, int K, f2* own_base, int OLD, int cov0, int cov1,
+                                            int kpi, int jf, double vr, double vi, double dr, double di, double plane_scale)
 {
     const double den = vr * vr + vi * vi;
     double shift = (dr * vi - di * vr) / den;
@@ -382,85 +369,95 @@ __device__ __forceinline__ void resolve_one(int* tq, int e, int n_in, f2* disp_b
     const double a = static_cast<double>(kpi) + shift;
     const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
     const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
-    if (e < n_in) {
+    if (kpi >= cov0 && kpi < cov1) {
         f2* cell = own_base + jf * OLD + (kpi - cov0);
         const f2 V = *cell;
         move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, V, cell, true);
     } else {
-        constexpr int QI = tie_queue_in(NWIN);
-        const int* q = tq + 4 + QI / 2 + 3 * (e - n_in);
-        move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, f2{__int_as_float(q[1]), __int_as_float(q[2])}, nullptr, false);
+        const double sg = (kpi & 1) ? -plane_scale : plane_scale;
+        const f2 V = {static_cast<float>(vr * sg), static_cast<float>(vi * sg)};
+        move_source<NWIN, true>(disp_base + jf * LDF, flag, klo, K, kpi, row, V, nullptr, false);
     }
 }
 
-// (`sample(i)` = sample i of the group's first frame as a double: the float tile of fsst_core128_kernel, or the decoded
-//  half-pair records of fsst_canon128.hpp)
 template <int NWIN, class Sample>
-__device__ __forceinline__ void resolve_ties_with(int* tq, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
-                                             f2* own_base, int OLD, int cov0,
-                                             const double* wtab, const double* twtab, int lane)
+__device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                               f2* own_base, int OLD, int cov0, int cov1,
+                                               const double* wtab, const double* twtab, double plane_scale, int lane_in)
 {
-    constexpr int QI = tie_queue_in(NWIN);
-    const int n_in = min(__builtin_amdgcn_readfirstlane(tq[0]), QI);
-    const int qn = n_in + min(__builtin_amdgcn_readfirstlane(tq[1]), kTieQueueOut);
-    auto meta_of = [&](int e) -> int {                 // bin | frame << 16 of entry e of the combined list
-        if (e < n_in) {
-            const int m = reinterpret_cast<const unsigned short*>(tq + 4)[e];
-            return (m & 0x1ff) | ((m >> 9) << 16);
-        }
-        return tq[4 + QI / 2 + 3 * (e - n_in)];
-    };
-    if (qn > kTieCoop) {
-        // many cells (tonal signals: every leakage bin of a frame is small and far-moving): ONE CELL PER LANE, the 4 nwin
-        // float64 multiply-adds of its bin in sequence (window pair: one address for the wave; twiddle: per lane from
-        // the 16 nwin byte table) -- 64 cells for about the price of six cooperative ones; rounds of 64
-        for (int base = 0; base < qn; base += 64) {
-            const int e = base + lane;
-            const bool act = e < qn;
-            const int meta = act ? meta_of(e) : 0;
-            const int kpi = meta & 0xffff, jf = meta >> 16;
-            double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 8
-            for (int n = 0; n < NWIN; ++n) {                // (unrolled: eight table loads in flight)
-                const double x = sample(jf + n);
-                const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-                const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
-                const double xw = x * wd.x, xd = x * wd.y;
-                vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-                dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+    constexpr int NSETS = NWIN / 128;                   // sets of 32 words = 64 sources
+    int lane = lane_in;                                 // opaque HERE, inside the rare branch: nothing this function derives
+    asm volatile("" : "+v"(lane));                      // from the lane id is computed per chunk, held across the transform and spilled
+#pragma unroll 1
+    for (int set = 0; set < NSETS; ++set) {
+        unsigned* tbs = tb + 32 * set;
+        const int k0 = 64 * set;
+        unsigned w = (lane < 32) ? tbs[lane] : 0u;
+        const int cnt = __popc(w);                       // <= 32 per lane: the wave's total from six ballots (scalar unit only)
+        int total = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((cnt >> b) & 1)) << b;
+        if (total == 0) continue;
+        if (total <= kTieCoop) {
+            // few cells: one by one, all lanes on one cell (NWIN / 64 taps per lane, float64 butterfly sum)
+            for (int it = 0; it < total; ++it) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(w != 0u);
+                const int l0 = __builtin_ctzll(mask);
+                const unsigned ww = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w), l0));
+                const int bit = __builtin_ctz(ww);
+                if (lane == l0) w &= w - 1u;
+                const int kpi = k0 + 2 * l0 + (bit >> 4), jf = bit & 15;
+                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll 1
+                for (int n = lane; n < NWIN; n += 64) {
+                    const double x = sample(jf + n);
+                    const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+                    const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+                    const double xw = x * wd.x, xd = x * wd.y;
+                    vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                    dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
+                    dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
+                }
+                if (lane == 0) resolve_one<NWIN>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
             }
-            if (act) resolve_one<NWIN>(tq, e, n_in, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, kpi, jf, vr, vi, dr, di);
+        } else {
+            // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = k0 + l and
+            // walks the frames whose bit is set -- at most 16 rounds, every round a full float64 DFT per lane (the window
+            // pair: one address for the wave; the twiddle: per lane from the 16 nwin byte table)
+            unsigned hw = (tbs[lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
+            const int kpi = k0 + lane;
+            while (__builtin_amdgcn_ballot_w64(hw != 0u) != 0ull) {
+                const bool act = hw != 0u;
+                const int jf = act ? __builtin_ctz(hw) : 0;
+                hw &= hw - 1u;
+                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll 1
+                for (int n = 0; n < NWIN; ++n) {
+                    const double x = sample(jf + n);
+                    const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
+                    const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+                    const double xw = x * wd.x, xd = x * wd.y;
+                    vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                    dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                }
+                if (act) resolve_one<NWIN>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
+            }
         }
-    } else
-    for (int e = 0; e < qn; ++e) {
-        const int meta = __builtin_amdgcn_readfirstlane(meta_of(e));
-        const int kpi = meta & 0xffff, jf = meta >> 16;
-        double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll
-        for (int n = lane; n < NWIN; n += 64) {
-            const double x = sample(jf + n);
-            const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-            const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
-            const double xw = x * wd.x, xd = x * wd.y;
-            vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-            dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
-            dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
-        }
-        if (lane == 0) resolve_one<NWIN>(tq, e, n_in, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, kpi, jf, vr, vi, dr, di);
+        if (lane < 32) tbs[lane] = 0u;
     }
-    if (lane == 0) { tq[0] = 0; tq[1] = 0; }
+    if (lane == 0) flag[1] = 0;
 }
 template <int NWIN>
 __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_base, int LDF, int* flag, int klo, int K,
-                                             f2* own_base, int OLD, int cov0,
+                                             f2* own_base, int OLD, int cov0, int cov1,
                                              const double* wtab, const double* twtab, int lane)
 {
-    resolve_ties_with<NWIN>(tq, [xg](int i) -> double { return static_cast<double>(xg[i]); }, disp_base, LDF, flag, klo, K, own_base, OLD, cov0,
-                       wtab, twtab, lane);
+    resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), [xg](int i) -> double { return static_cast<double>(xg[i]); }, disp_base, LDF, flag,
+                         klo, K, own_base, OLD, cov0, cov1, wtab, twtab, 1.0, lane);
 }
 
 // One one-sided source bin k' held as packed spectrum value X = Z[k'] with conjugate partner
@@ -562,7 +559,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
-    int* tq = flag + 4;                                                       // rounding-tie queues (tie_words(NWIN))
+    int* tq = flag + 4;                                                       // rounding-tie bitmap (tie_words(NWIN))
 
     // shared MFMA A operand, regrouped so that a lane reads all k-steps of a tap with one LDS instruction:
     // global [pass * 16 + tap][k-step][lane]  ->  LDS [pass * 16 + tap][lane][k-step]
@@ -572,7 +569,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
+    if (lane < 4) flag[lane] = 0;
+    for (int i = lane; i < tie_words(NWIN); i += 64) tq[i] = 0;
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
     if constexpr (FUSED) {
         if (wv == 0) {
@@ -762,7 +760,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     const float* xsig = p.x + b * p.xstride;
     auto stage_tile = [&](int t0) -> float {             // xs[i] = xpad[t0 + i] = x[t0 + i - 64]; returns sum x^2 (per lane)
         float e = 0.0f;
-        for (int i = lane_o; i < FPW + NWIN - 1; i += 64) {
+        int lane_t = lane;                               // (opaque per tile: the tile's lane addresses are not hoisted out of
+        asm volatile("" : "+v"(lane_t));                 //  the chunk loop, held across the transform and spilled)
+        for (int i = lane_t; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;
             const float v = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
             xs[i] = v;
@@ -861,9 +861,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         wave_sync();
         // one LDS round trip for both per-group flags (dirty displaced plane, queued rounding ties)
         int f_dirty = flag[0];
-        const int f_ties = tq[0] | tq[1];
+        const int f_ties = flag[1];
         if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
-            resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, p.wtab, p.twtab, lane_o);
+            resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, RQ * (s1 + 1), p.wtab, p.twtab, lane_o);
             wave_sync();
             f_dirty = flag[0];
         }

@@ -122,7 +122,10 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     if constexpr (CANON) {
         if (lane < 4) flag[lane] = 0;
         if (lane < kCanonTieWords) tq[lane] = 0;
-    } else if (lane == 0) { *flag = 0; tq[0] = 0; tq[1] = 0; }
+    } else {
+        if (lane < 4) flag[lane] = 0;
+        for (int i = lane; i < tie_words(NWIN); i += 64) tq[i] = 0;
+    }
     if (threadIdx.x < 8) next_q[threadIdx.x] = 0;
     if (threadIdx.x >= 8 && threadIdx.x < 16) next_q[threadIdx.x] = 0x7fffffff;      // pend[]: nothing unresolved
     // Block identity = ARRIVAL number, not blockIdx: the blocks that are running always hold the identities 0 .. R - 1, so
@@ -405,9 +408,9 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 if (s1 == NT / 2 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[NT / 2].x, 0.0f};
                 wave_sync();
                 int f_dirty = flag[0];
-                const int f_ties = tq[0] | tq[1];
+                const int f_ties = flag[1];
                 if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {
-                    resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, p.wtab, p.twtab, lane_o);
+                    resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, RQ * (s1 + 1), p.wtab, p.twtab, lane_o);
                     wave_sync();
                     f_dirty = flag[0];
                 }
