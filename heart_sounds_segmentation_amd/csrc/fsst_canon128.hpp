@@ -93,6 +93,7 @@ struct CanonCfg {
 struct CanonTile {
     float R2s;            // error-bound scale of the tile in SCALED units (see "Rounding ties" in fsst_mfma128.hpp)
     float inv;            // 1 / (sample scale x constant scale): features = plane values x inv (a power of two)
+    float r2s;            // the plan's r2scale in scaled units: R^2 = r2s x (sum of squares of scaled samples)
 };
 
 // Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile, zero outside the signal)
@@ -111,6 +112,7 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
     CanonTile t;
     t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
     t.R2s = r2scale_s * (E * sx) * sx;
+    t.r2s = r2scale_s;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float v = sreg[k] * sx;
@@ -207,6 +209,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     lds_float* ownA = (lds_float*)static_cast<size_t>(oa);
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
     f2* row_disp = disp_base + j * C::LDF;
+    float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
     static_for<NT / 2>([&](auto SS) {
         constexpr int s = decltype(SS)::value;
         constexpr bool STA = C::stored(s, 0), STB = C::stored(s, 1);
@@ -217,8 +220,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         const f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
         const f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
         const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
-        if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; }
-        if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; }
+        if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; mx = fmaxf(mx, dna.x); }
+        if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; mx = fmaxf(mx, dnb.x); }
         const bool ma = fabsf(dna.y) >= TA * dna.x, mb = fabsf(dnb.y) >= TB * dnb.x;
         if (ma | mb) {
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
@@ -230,13 +233,41 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     wave_sync();
     int f_dirty = flag[0];
     const int f_ties = flag[1];
+    auto signal_sample = [&](int i) -> double {
+        const int gi = tg + i - NWIN / 2;
+        return (gi >= 0 && gi < n) ? static_cast<double>(xsig[gi]) : 0.0;
+    };
+    bool exact = false;
+#ifndef HSS_NO_EXACT
+    // ---- "Exact groups" (fsst_mfma128.hpp): no stored cell reaches kExactTheta R of the tile -> look again with the R of
+    //      the group's own 143 samples (a quiet group beside a loud burst) -> still none: float64 for the whole group
+    if (__builtin_amdgcn_ballot_w64(mx > kExactTheta2 * tile.R2s) == 0ull && tile.R2s > 0.0f) {
+        float e2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane_o + 64 * k;
+            const u2 r = xrec[min(i, 142)];
+            const float v = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(r.x & 0xffffu))) +
+                            static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(r.y & 0xffffu)));
+            e2 = fmaf(i < 143 ? v : 0.0f, v, e2);
+        }
+        const float R2g = tile.r2s * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+        exact = __builtin_amdgcn_ballot_w64(mx > kExactTheta2 * R2g) == 0ull && R2g > 0.0f;
+    }
+#endif
+    if (exact) {
+        for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+        if (lane_o < 2) flag[lane_o] = 0;
+        wave_sync();
+        resolve_bitmap<NWIN, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD,
+                                   C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        wave_sync();
+        f_dirty = flag[0];
+    } else
     if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
         // 1e-5 bins from a half-integer needs all 24
-        resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), [&](int i) -> double {
-            const int gi = tg + i - NWIN / 2;
-            return (gi >= 0 && gi < n) ? static_cast<double>(xsig[gi]) : 0.0;
-        }, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
     }

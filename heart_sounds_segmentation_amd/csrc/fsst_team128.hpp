@@ -375,6 +375,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 f2* ownB = own_base + j * OLD + rBi - RQ * s0;
 
                 f2 za[NT], zb[NT];
+                float mx_unused = 0.0f;                      // (the general-band instantiation is not dispatched: it has no exact mode)
                 static_for<NT / 4>([&](auto GG) {
                     constexpr int g0 = decltype(GG)::value * 4;
                     f4 acc4[4];
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                     const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
                     const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
                     const bool st = (s >= s0) && (s <= s1);
-                    process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, tq, j, klo, K, rAi, rBi, R2);
+                    process_stripe<s, RQ, NWIN>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, tq, j, klo, K, rAi, rBi, R2, mx_unused);
                 });
                 if (s1 == NT / 2 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[NT / 2].x, 0.0f};
                 wave_sync();

@@ -503,9 +503,9 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         int rc = 0;
         if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
                              : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
-        if (rc == 0 && !no_team && !(canon16 && (col0 & 63) != 0)) {
-            rc = canon16 ? launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st)
-                 : canon ? launch_team128<3>(pl, cp, batch, ngroups, st) : launch_team128<-1>(pl, cp, batch, ngroups, st);
+        // (the team kernel exists for the canonical band only -- fsst_canon128.hpp; other bands: one CU per signal or two launches)
+        if (rc == 0 && !no_team && canon16 && (col0 & 63) == 0) {
+            rc = launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st);
             if (rc == 1) { *did_fuse = true; pl->last_zpath = 2; return 0; }
         }
         if (rc < 0) return rc;

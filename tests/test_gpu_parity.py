@@ -538,6 +538,76 @@ def test_pure_tones_heavy_windows(oracle_mod, wname, nwin):
                 parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=f"{wname}({nwin}) tone {f0} {mode} sig{b}")
 
 
+# Structured signals on which float32 is at its limit (tools/adversarial_parity.py, profiles/r02_adversarial_parity.txt: 279 of
+# 1 500 such cases missed the gate in round 2): the band holds only the far leakage of an out-of-band component, an offset
+# or a step 100 times the in-band content, clean tones / chirps under low-sidelobe windows (every leakage cell undecided).
+def _adversarial_signals():
+    from scipy.signal import square, sawtooth, chirp
+    fs, n = 1000.0, 1536
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(0)
+    sig = {
+        "tone 125": np.cos(2 * np.pi * 125.0 * t),
+        "tone 117.3": np.cos(2 * np.pi * 117.3 * t),
+        "two close tones": np.cos(2 * np.pi * 100.0 * t) + 0.8 * np.cos(2 * np.pi * 104.0 * t),
+        "square 40": square(2 * np.pi * 40.0 * t),
+        "sawtooth 33": sawtooth(2 * np.pi * 33.0 * t),
+        "impulses": (np.arange(n) % 97 == 0).astype(np.float64),
+        "step": (t > 0.7).astype(np.float64) + 0.25,
+        "chirp 20-400": chirp(t, 20.0, t[-1], 400.0),
+        "tone + 1e-4 noise": np.cos(2 * np.pi * 60.0 * t) + 1e-4 * rng.standard_normal(n),
+        "big dc + tone": 100.0 + np.cos(2 * np.pi * 80.0 * t),
+    }
+    return fs, list(sig), np.stack([sig[k] for k in sig]).astype(np.float32)
+
+
+# (window length, window, band, mode, signal) combinations of that sweep that still miss the gate: all rows kept (the offset's
+# own row is in the band and IS the largest feature, so the group is "loud" and stays in float32), z-scored, an offset / step 100
+# times the rest: 1.1-1.9e-4 in rel-L2, one at 1.5e-4 in max -- README "Limits".  Kept as expected failures so that an
+# improvement (or a regression elsewhere) shows.
+_ADV_KNOWN = {
+    (256, "flattop", None, "stack", "step"),
+    (512, "hann", None, "stack", "big dc + tone"), (512, "blackman", None, "stack", "big dc + tone"),
+    (512, "kaiser10", None, "stack", "big dc + tone"),
+    (512, "flattop", None, "stack", "step"), (512, "flattop", None, "stack", "big dc + tone"),
+}
+
+
+@pytest.mark.parametrize("nwin", [128, 256, 512])
+@pytest.mark.parametrize("wname", ["kaiser0.5", "hann", "blackman", "kaiser10", "flattop"])
+def test_adversarial_structured_signals(oracle_mod, wname, nwin):
+    """The structured sweep of tools/adversarial_parity.py under -m gpu: 10 signals x 3 bands x stack / raw per (window,
+    length), the gate of tests/parity.py with no allowance.  What changed since round 2: undecided roundings are a bitmap (no
+    queue to overflow: the chirp / tone + noise misses), and a group none of whose stored cells reaches 1e-2 of its own
+    spectrum-norm bound is redone in float64 (the empty-band and offset misses).  The canonical band at 128 points passes on
+    every window and signal; _ADV_KNOWN lists the 6 of 900 that are left (the generic kernel of nwin 32 / 64 and the any-length
+    kernel have the bitmap-free tie paths of round 2 and no exact mode: tools/adversarial_parity.py 64 100 lists their misses)."""
+    from scipy.signal import get_window
+    fs, names, X = _adversarial_signals()
+    spec = {"kaiser0.5": ("kaiser", 0.5), "kaiser10": ("kaiser", 10.0)}.get(wname, wname)
+    w = get_window(spec, nwin, fftbins=False)
+    unexpected, fixed = [], []
+    for band in [(25, 200), None, (300, 450)]:
+        for mode in ("stack", "raw"):
+            tf = FSST(fs, w, truncate_freq=band, stack=(mode == "stack"))
+            got = tf.batch(torch.from_numpy(X).cuda()).cpu().numpy()
+            ref, hd = oracle_mod.features(X, fs, w, band, mode, return_halfdist=True)
+            for b, nm in enumerate(names):
+                if mode == "stack" and not np.isfinite(ref[b]).all():
+                    continue
+                key = (nwin, wname, band, mode, nm)
+                try:
+                    parity.check(got[b], ref[b], hd[b], 1 if mode == "raw" else 0, what=str(key))
+                    if key in _ADV_KNOWN:
+                        fixed.append(key)
+                except AssertionError as e:
+                    if key not in _ADV_KNOWN:
+                        unexpected.append(str(e)[:160])
+    assert not unexpected, unexpected
+    if fixed:
+        print("adversarial cases listed as known misses that now pass:", fixed)
+
+
 def test_corpus_builder_and_end_to_end(oracle_mod):
     """the batched dataset builder yields what the reference's loop would
     (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,
@@ -870,7 +940,7 @@ def test_stack_over_a_column_range(batch, col0):
     tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
     cols = (col0, 1696)                                    # 106 groups: inside the fused kernel's range
     got = tf._run(X, cols=cols)
-    want_path = 1 if batch >= 256 else (0 if (col0 % 16 == 0 and col0 % 64) else 2)     # (the team kernels' chunks are whole tiles)
+    want_path = 1 if batch >= 256 else (2 if col0 % 64 == 0 else 0)     # (the team kernel's chunks are whole tiles)
     assert tf.check() == want_path or torch.cuda.get_device_properties(0).multi_processor_count != 256
     raw = tf.unnormalized(X, cols=cols).double()
     assert got.shape == raw.shape == (batch, 1696, 44)
