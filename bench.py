@@ -63,7 +63,7 @@ def pmc_profile(kernel_substr):
     return None
 
 
-def live_traffic(kernel_substr, batch, timeout_s=150):
+def live_traffic(kernel_substr, batch, timeout_s=150, extra_env=None):
     """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two short child runs of this very script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no tracing, as MI355X_MICROARCH.md prescribes:
     counter values are KiB per dispatch, FETCH_SIZE reports half of a wide streaming read on gfx950 and is doubled).
@@ -78,6 +78,8 @@ def live_traffic(kernel_substr, batch, timeout_s=150):
         return None
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp")
+    if extra_env:
+        env.update(extra_env)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         td = tempfile.mkdtemp(prefix="hss_pmc_", dir="/tmp")
         try:
@@ -468,6 +470,31 @@ def main():
                 roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
                                      f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
                                      f"per launch (profiles/r03_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
+        # the same workload on the team kernel (every feature written once: algorithmic HBM traffic), beside the default path
+        if world == 1 and not args.no_extras and fused == 1 and not os.environ.get("HSSFSST_NO_CANON"):
+            try:
+                tf.set_zpath("team", local)
+                for _ in range(50):
+                    tf.batch(X, out=out)
+                torch.cuda.synchronize(dev)
+                tf.set_timing(True, local)
+                for _ in range(min(args.steps, 500)):
+                    tf.batch(X, out=out)
+                t_ms, _, t_n = tf.timing(local)
+                tf.set_timing(False, local)
+                t_path = tf.check(local)
+                tf.set_zpath("auto", local)
+                if t_path == 2 and t_n > 0:
+                    tl = live_traffic("fsst_team128_kernel<3, 4, 22>", B, extra_env={"HSSFSST_TEAM_ONLY": "1"})
+                    t_avg = t_ms / t_n
+                    roof["team_kernel"] = {"kernel": "fsst_team128_kernel<3, 4, 22> (transform + z-score in one launch: teams of CUs, features "
+                                                     "z-scored in registers and written once; bit-identical output)",
+                                           "avg_launch_ms": round(t_avg, 4), "achieved": round(alg / (t_avg * 1e-3) / 1e9, 2),
+                                           "frac": round(alg / (t_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "traffic": tl["hbm_bytes_per_launch"] if tl else None,
+                                           "traffic_over_algorithmic": round(tl["hbm_bytes_per_launch"] / alg, 3) if tl else None}
+            except Exception as e:                               # never lose the bench line to the side measurement
+                roof["team_kernel"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         line = {
             "metric": "PCG windows/sec FSST (1 kHz, 2000-sample)", "value": round(value, 1),
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -118,6 +118,8 @@ def lib():
         L.hssfsst_stream_step.argtypes = [vp, vp, c_i64, c_i64, vp, c_i64, c_int, c_int, c_int, vp, vp, vp, vp]
         L.hssfsst_stream_step.restype = c_int
         L.hssfsst_plan_last_exec_fused.argtypes = [vp]
+        L.hssfsst_plan_set_zpath.argtypes = [vp, c_int]
+        L.hssfsst_plan_set_zpath.restype = c_int
         L.hssfsst_plan_last_exec_fused.restype = c_int
         L.hssfsst_plan_check.argtypes = [vp]
         L.hssfsst_plan_check.restype = c_int

@@ -447,9 +447,9 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
                 const int jf = act ? __builtin_ctz(hw) : 0;
                 hw &= hw - 1u;
                 double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 1
-                for (int n = 0; n < NWIN; ++n) {
-                    const double x = sample(jf + n);
+#pragma unroll 4
+                for (int n = 0; n < NWIN; ++n) {                 // (unrolled: four table / sample loads in flight; not unrolled
+                    const double x = sample(jf + n);             //  every tap waits out a full memory latency: 80x on nwin 512)
                     const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
                     const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
                     const double xw = x * wd.x, xd = x * wd.y;

@@ -168,6 +168,7 @@ struct hssfsst_plan {
     unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: arrival counter and its value after the launches so far
     int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
     int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
+    int zpath_pref = 0;                                      // HSSFSST_ZPATH_*: preference among the z-score paths
     int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
@@ -498,8 +499,10 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         // (16 waves per CU, the tile makes one HBM round trip inside the launch: 0.245 ms per 1024 windows); every other
         // shape -- small or ragged batches, short signals -- the team kernel (8 waves per CU, features written once from
         // registers: 0.258 ms per 1024 windows, but 1.2-1.9x faster than two launches where the former does not apply)
-        static const bool no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;         // A/B and tests
-        static const bool team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr;     // A/B and tests
+        static const bool env_no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;     // A/B and tests
+        static const bool env_team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr; // A/B and tests
+        const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
+        const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
         if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
                              : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
@@ -828,6 +831,13 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
 
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? p->last_zpath : 0; }
 
+int hssfsst_plan_set_zpath(hssfsst_plan* p, int zpath)
+{
+    if (!p || zpath < HSSFSST_ZPATH_AUTO || zpath > HSSFSST_ZPATH_TEAM) return fail(HSSFSST_EINVAL, "plan_set_zpath: bad argument");
+    p->zpath_pref = zpath;
+    return 0;
+}
+
 int hssfsst_plan_check(hssfsst_plan* p)
 {
     if (!p) return fail(HSSFSST_EINVAL, "plan_check: plan is NULL");
@@ -1049,7 +1059,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             };
             rc = (G == 4) ? launch(hssfsst::fsst_dft_kernel<4>) : (G == 2) ? launch(hssfsst::fsst_dft_kernel<2>) : launch(hssfsst::fsst_dft_kernel<1>);
         } else if (use128) {
-            rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st, !no_fused && !piped, &did_fuse);
+            rc = launch_core128(p, cx, x_stride, cout, cp.partials, n, col0, ncols, cb, st, !no_fused && !piped && p->zpath_pref != HSSFSST_ZPATH_TWO_LAUNCH, &did_fuse);
         } else switch (p->R) {
             case 1: rc = launch_core<1>(p, cp, cblocks, st); break;
             case 2: rc = launch_core<2>(p, cp, cblocks, st); break;

@@ -270,6 +270,13 @@ class FSST:
         _lib.check(_lib.lib().hssfsst_plan_check(plan.handle), "hssfsst_plan_check")
         return int(_lib.lib().hssfsst_plan_last_exec_fused(plan.handle))
 
+    def set_zpath(self, zpath: str = "auto", device_index: Optional[int] = None) -> None:
+        """Extension: preference among the z-score paths of the following ``stack`` calls on that device's plan --
+        "auto" (the fastest that applies), "two_launch", "one_cu", "team".  Results do not depend on it (bit-identical)."""
+        dev = self._device_index() if device_index is None else device_index
+        code = {"auto": 0, "two_launch": 1, "one_cu": 2, "team": 3}[zpath]
+        _lib.check(_lib.lib().hssfsst_plan_set_zpath(self._plan(dev).handle, code), "hssfsst_plan_set_zpath")
+
     def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
         """Extension (bench): record HIP events around the kernels of every following call."""
         dev = self._device_index() if device_index is None else device_index

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 203
+#define HSSFSST_VERSION 204
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -111,6 +111,15 @@ int hssfsst_plan_check(hssfsst_plan* plan);
  * signals), 2 = the team kernel (every other batch of signals up to 4096 samples: features stay in registers until
  * the signal's statistics arrive from the team).  All three give bit-identical results. */
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* plan);
+
+/* Preference among those paths for the plan's following STACK execs: HSSFSST_ZPATH_AUTO (default: the fastest that
+ * applies), HSSFSST_ZPATH_TWO_LAUNCH, HSSFSST_ZPATH_ONE_CU (else two launches), HSSFSST_ZPATH_TEAM (else two launches).  A
+ * path that does not apply to a shape (see above) is never forced.  Results do not depend on the choice. */
+#define HSSFSST_ZPATH_AUTO 0
+#define HSSFSST_ZPATH_TWO_LAUNCH 1
+#define HSSFSST_ZPATH_ONE_CU 2
+#define HSSFSST_ZPATH_TEAM 3
+int hssfsst_plan_set_zpath(hssfsst_plan* plan, int zpath);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in

@@ -608,6 +608,29 @@ def test_adversarial_structured_signals(oracle_mod, wname, nwin):
         print("adversarial cases listed as known misses that now pass:", fixed)
 
 
+@pytest.mark.parametrize("batch", [300, 512])
+def test_zpath_preference_is_bit_identical(batch):
+    """hssfsst_plan_set_zpath (FSST.set_zpath): two launches, one CU per signal and the team kernel on the same plan, same
+    input -- the same bits; the reported path is the requested one where it applies (one CU per signal needs a batch that
+    nearly fills the chip's CUs: 300 does not on 256 CUs, and is then two launches)."""
+    X = torch.from_numpy(synth.pcg_windows(batch, 2000, seed=batch)).cuda()
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    full_chip = torch.cuda.get_device_properties(0).multi_processor_count == 256
+    ref = None
+    for zp, want in (("two_launch", 0), ("team", 2), ("one_cu", 1 if batch == 512 else 0), ("auto", None)):
+        tf.set_zpath(zp)
+        got = tf.batch(X)
+        path = tf.check()
+        if want is not None and full_chip:
+            assert path == want, (zp, path)
+        if ref is None:
+            ref = got.clone()
+        else:
+            assert torch.equal(got, ref), zp
+    with pytest.raises(KeyError):
+        tf.set_zpath("fastest")
+
+
 def test_corpus_builder_and_end_to_end(oracle_mod):
     """the batched dataset builder yields what the reference's loop would
     (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,
