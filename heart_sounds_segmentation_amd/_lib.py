@@ -139,6 +139,8 @@ def lib():
         L.hssfsst_moments_merge.restype = c_int
         L.hssfsst_parse_signal_csv.argtypes = [ctypes.c_char_p, c_i64, vp, vp, c_i64]
         L.hssfsst_parse_signal_csv.restype = c_i64
+        L.hssfsst_pack_recordings.argtypes = [vp, vp, c_i64, c_int, c_int, vp, c_i64, vp, c_i64, c_int]
+        L.hssfsst_pack_recordings.restype = c_i64
         L.hssfsst_resample.argtypes = [dp, c_i64, c_i64, dp]
         L.hssfsst_resample.restype = c_int
         L.hssfsst_device_count.restype = c_int

@@ -202,8 +202,10 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         });
         __builtin_amdgcn_sched_barrier(0);
     });
+#if !defined(HSS_CANON_ABLATE) || HSS_CANON_ABLATE < 5
     fft_n<NT>(za);
     fft_n<NT>(zb);
+#endif
 
     // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
     unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
@@ -213,7 +215,14 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
     f2* row_disp = disp_base + j * C::LDF;
     float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
+#if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 4
+    {   f2 accz = {0.0f, 0.0f};
+        static_for<NT>([&](auto I) { accz += za[decltype(I)::value] + zb[decltype(I)::value]; });
+        ownA[0] = accz.x; ownA[1] = accz.y; mx = 1.0e30f; }
+    static_for<0>([&](auto SS) {
+#else
     static_for<NT / 2>([&](auto SS) {
+#endif
         constexpr int s = decltype(SS)::value;
         constexpr bool STA = C::stored(s, 0), STB = C::stored(s, 1);
         constexpr float TA = C::thr(s, 0), TB = C::thr(s, 1);
@@ -226,7 +235,11 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; mx = fmaxf(mx, dna.x); }
         if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; mx = fmaxf(mx, dnb.x); }
         const bool ma = fabsf(dna.y) >= TA * dna.x, mb = fabsf(dnb.y) >= TB * dnb.x;
+#if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 3      // development (tools/canon_ablate.sh): results invalid
+        if ((ma | mb) && tile.R2s == 123.0f) {
+#else
         if (ma | mb) {
+#endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
             if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, cellA, STA);
@@ -571,12 +584,21 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
             const int tg = p.col0 + gidx * 16;
             canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg);
             const int nvalid = min(16, cend - tg);
+#if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 2
+            if (p.mode == 77) {
+#else
             if (p.mode == kModeStack) {
+#endif
                 f2 piv;
                 const float w = canon_stats<KLO, KC>(own_base, nvalid, tile.inv, lane_o, piv);
                 if constexpr (FUSED) store_partial(part_lds + ((static_cast<int>(ksig) & 1) * kFusedMaxGroups + gidx) * kPartFloats, w, piv.x, piv.y);
                 else store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
             }
+#if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 1
+            if (tg == 123456789) {
+#else
+            {
+#endif
             f4 o[3];
             canon_image<KLO, KC>(own_base, ppk_lds, tile.inv, lane_o, o);
             float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + (tg - p.col0)) * (2 * K)) + lane_o;
@@ -588,6 +610,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
                     if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
                     else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
                 }
+            }
             }
             wave_sync();
         }

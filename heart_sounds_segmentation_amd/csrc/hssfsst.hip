@@ -13,6 +13,7 @@
 #include <cstring>
 #include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "fsst_kernels.hpp"
@@ -1182,6 +1183,46 @@ int hssfsst_resample(const double* x, int64_t n, int64_t num, double* y)
         return fail(HSSFSST_ENOMEM, "hssfsst_resample: out of host memory");
     }
     return 0;
+}
+
+int64_t hssfsst_pack_recordings(const float* const* ptrs, const int64_t* lens, int64_t count, int stride, int n,
+                                float* stage, int64_t stage_cap, int64_t* starts, int64_t starts_cap, int threads)
+{
+    if (!ptrs || !lens || !stage || !starts || count < 0 || stride < 1 || n < 1)
+        return fail(HSSFSST_EINVAL, "pack_recordings: bad argument");
+    std::vector<int64_t> pos(static_cast<size_t>(count) + 1, 0);
+    int64_t nf = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t T = lens[i];
+        if (T < 0 || !ptrs[i]) return fail(HSSFSST_EINVAL, "pack_recordings: recording %lld is NULL or negative", static_cast<long long>(i));
+        pos[i + 1] = pos[i] + T;
+        // frame_signal: L = floor((T - n) / stride) frames, one fewer than fit; L <= 0 -> the single frame x[:n]
+        int64_t L = (T - n >= 0) ? (T - n) / stride : -1;
+        if (L <= 0) L = 1;
+        if (nf + L > starts_cap) return fail(HSSFSST_EINVAL, "pack_recordings: more than %lld frames", static_cast<long long>(starts_cap));
+        for (int64_t k = 0; k < L; ++k) starts[nf + k] = pos[i] + k * stride;
+        nf += L;
+    }
+    const int64_t total = pos[count];
+    if (total > stage_cap) return fail(HSSFSST_EINVAL, "pack_recordings: %lld samples exceed the staging capacity %lld",
+                                       static_cast<long long>(total), static_cast<long long>(stage_cap));
+    int nt = threads > 0 ? threads : static_cast<int>(total / (1 << 20)) + 1;     // one thread per 4 MB of float32
+    if (nt > 8) nt = 8;
+    if (nt > count) nt = static_cast<int>(count > 0 ? count : 1);
+    auto work = [&](int t) {
+        // thread t copies the recordings whose first sample falls into its share of the staging buffer
+        const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        for (int64_t i = 0; i < count; ++i)
+            if (pos[i] >= lo && pos[i] < hi && lens[i] > 0) std::memcpy(stage + pos[i], ptrs[i], static_cast<size_t>(lens[i]) * sizeof(float));
+    };
+    if (nt <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    return nf;
 }
 
 int64_t hssfsst_parse_signal_csv(const char* text, int64_t len, float* signals, int64_t* labels, int64_t cap)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 204
+#define HSSFSST_VERSION 205
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -179,6 +179,15 @@ int hssfsst_stream_step(hssfsst_plan* plan, float* tape, int64_t tape_len, int64
  * integral label columns).  Fills at most `cap` rows; returns the number of data rows in the file
  * (call once with cap = 0 to size the buffers) or a negative status on a malformed line. */
 int64_t hssfsst_parse_signal_csv(const char* text, int64_t len, float* signals, int64_t* labels, int64_t cap);
+
+/* Host helper of the batched dataset builder (/root/reference/hss/datasets/heart_sounds.py:155-169 +
+ * hss/utils/preprocess.py:30-58, many recordings per call): copies `count` host recordings (float32, contiguous, lens[i]
+ * samples at ptrs[i]) back to back into `stage` and writes the start, inside `stage`, of every frame frame_signal would
+ * emit for them -- L = floor((T - n) / stride) frames i * stride, or ONE frame at 0 when L <= 0 (the caller has already
+ * dropped recordings shorter than n) -- into `starts` (capacity starts_cap).  Uses up to `threads` host threads for the
+ * copies (<= 0: one per 4 MB, at most 8).  Returns the number of frames written, or a negative status. */
+int64_t hssfsst_pack_recordings(const float* const* ptrs, const int64_t* lens, int64_t count, int stride, int n,
+                                float* stage, int64_t stage_cap, int64_t* starts, int64_t starts_cap, int threads);
 
 /* Host helper, no device needed: replaces Resample.__call__ (hss/transforms/resample.py:13-21), i.e.
  * scipy.signal.resample(x, num) for a real 1-D sequence (Fourier method, window=None): y[0..num) from x[0..n).

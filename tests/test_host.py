@@ -198,3 +198,33 @@ def test_corpus_builder_groups_recordings_like_the_reference_loop():
     parts = [build_features(recs, Identity(), device="cpu", rank=r, world=3) for r in range(3)]
     flat = [it for p in parts for it in p]
     assert len(flat) == len(want) and all(torch.equal(a[0][:, 0], b[0]) for a, b in zip(flat, want))
+
+
+def test_pack_recordings_equals_python_framing(built_lib):
+    """hssfsst_pack_recordings (the corpus builder's host side, one native call per group of recordings): the staging
+    buffer is the recordings back to back and the frame starts are those of frame_signal
+    (/root/reference/hss/utils/preprocess.py:30-58 as restated by framing.frame_starts), for lengths at and around the
+    frame boundaries; capacity errors are reported, not overrun."""
+    import ctypes
+    from heart_sounds_segmentation_amd.framing import frame_starts
+    recs = [torch.randn(T) for T in (35500, 2000, 2999, 3000, 3001, 4001, 35000, 2000)]
+    ptrs = np.asarray([x.data_ptr() for x in recs], dtype=np.uint64)
+    lens = np.asarray([x.numel() for x in recs], dtype=np.int64)
+    stage = torch.empty(int(lens.sum()))
+    starts = torch.empty(256, dtype=torch.int64)
+    vp = ctypes.c_void_p
+    for threads in (1, 3, 0):
+        stage.zero_()
+        nf = built_lib.hssfsst_pack_recordings(vp(ptrs.ctypes.data), vp(lens.ctypes.data), len(recs), 1000, 2000, vp(stage.data_ptr()),
+                                               stage.numel(), vp(starts.data_ptr()), starts.numel(), threads)
+        want, base = [], 0
+        for x in recs:
+            want.append(frame_starts(x.numel(), 1000, 2000)[0] + base)
+            base += x.numel()
+        want = np.concatenate(want)
+        assert nf == len(want) and np.array_equal(starts[:nf].numpy(), want)
+        assert torch.equal(stage, torch.cat(recs))
+    assert built_lib.hssfsst_pack_recordings(vp(ptrs.ctypes.data), vp(lens.ctypes.data), len(recs), 1000, 2000, vp(stage.data_ptr()),
+                                             stage.numel() - 1, vp(starts.data_ptr()), starts.numel(), 1) < 0
+    assert built_lib.hssfsst_pack_recordings(vp(ptrs.ctypes.data), vp(lens.ctypes.data), len(recs), 1000, 2000, vp(stage.data_ptr()),
+                                             stage.numel(), vp(starts.data_ptr()), 10, 1) < 0
