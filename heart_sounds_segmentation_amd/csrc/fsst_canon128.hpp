@@ -238,7 +238,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 3      // development (tools/canon_ablate.sh): results invalid
         if ((ma | mb) && tile.R2s == 123.0f) {
 #else
-        if (ma | mb) {
+        if (__builtin_expect(ma | mb, 0)) {                  // (unlikely: the rare path is laid out behind the hot code, no taken branch over it)
 #endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
@@ -257,7 +257,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #ifndef HSS_NO_EXACT
     // ---- "Exact groups" (fsst_mfma128.hpp): no stored cell reaches kExactTheta R of the tile -> look again with the R of
     //      the group's own 143 samples (a quiet group beside a loud burst) -> still none: float64 for the whole group
-    if (__builtin_amdgcn_ballot_w64(mx > kExactTheta2 * tile.R2s) == 0ull && tile.R2s > 0.0f) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > kExactTheta2 * tile.R2s) == 0ull && tile.R2s > 0.0f, 0)) {
         float e2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         exact = __builtin_amdgcn_ballot_w64(mx > kExactTheta2 * R2g) == 0ull && R2g > 0.0f;
     }
 #endif
-    if (exact) {
+    if (__builtin_expect(exact, 0)) {
         for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
         if (lane_o < 2) flag[lane_o] = 0;
         wave_sync();
@@ -280,7 +280,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         wave_sync();
         f_dirty = flag[0];
     } else
-    if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {       // (rare) cells whose rounding float32 cannot decide
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(f_ties) != 0, 0)) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
         // 1e-5 bins from a half-integer needs all 24
         resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);

@@ -213,10 +213,57 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
                 land(jf, kp, static_cast<int>(row), __int_as_float(tq[5 + 3 * e]), __int_as_float(tq[6 + 3 * e]));
             }
         }
+        const int q_all = __builtin_amdgcn_readfirstlane(tq[0]);  // undecided cells drawn, including those the queue had no room for
         if (qn > 0) {
             if (lane == 0) tq[0] = 0;
             wave_sync();
         }
+#ifndef HSS_NO_EXACT
+        // ---- "Exact groups" (fsst_mfma128.hpp): the tile is redone in float64 when none of its kept cells reaches
+        //      kExactTheta R (the band holds only the far leakage of something outside it: float32 resolves ~4e-7 of the
+        //      frame's spectrum norm, not of the band), or when the tie queue overflowed (cells it had no room for were
+        //      rounded in float32).  Every (source, frame) cell: float64 DFT, the modified-STFT phase, float64 rounding, land.
+        {
+            float mxc = 0.0f;
+            for (int i = lane; i < F * LDP; i += 64) { const f2 v = plane[i]; mxc = fmaxf(mxc, fmaf(v.x, v.x, v.y * v.y)); }
+            const bool quiet = __builtin_amdgcn_ballot_w64(mxc > kExactTheta2 * R2) == 0ull && R2 > 0.0f;
+            if (quiet || q_all > kDftTieQueue) {
+                wave_sync();
+                for (int i = lane; i < F * LDP; i += 64) plane[i] = f2{0.0f, 0.0f};
+                wave_sync();
+                const int ncell = nf * F;
+                for (int base = 0; base < ncell; base += 64) {
+                    const int e = base + lane;
+                    const bool act = e < ncell;
+                    const int kp = act ? e / F : 0, jf = act ? e - kp * F : 0;
+                    double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+                    int ti = 0;
+#pragma unroll 4
+                    for (int nn = 0; nn < N; ++nn) {
+                        const double x = static_cast<double>(xs[jf + nn]);
+                        const double2 wd = reinterpret_cast<const double2*>(p.wtab)[nn];
+                        const double2 cs = reinterpret_cast<const double2*>(p.twtab)[ti];
+                        ti += kp; if (ti >= N) ti -= N;
+                        const double xw = x * wd.x, xd = x * wd.y;
+                        vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                        dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                    }
+                    if (act) {
+                        double shift = (dr * vi - di * vr) / (vr * vr + vi * vi);
+                        if (!(fabs(shift) <= 1.0e6)) shift = 0.0;
+                        const double a = static_cast<double>(kp) + shift;
+                        const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+                        long long row = static_cast<long long>(r) % N;
+                        if (row < 0) row += N;
+                        // the plane holds the modified STFT: V e^{-2 pi i m k' / N} (oracle/fsst_oracle.c step 5)
+                        const double2 ph = reinterpret_cast<const double2*>(p.twtab)[static_cast<unsigned>((static_cast<long long>(kp) * m) % N)];
+                        land(jf, kp, static_cast<int>(row), static_cast<float>(vr * ph.x + vi * ph.y), static_cast<float>(vi * ph.x - vr * ph.y));
+                    }
+                }
+                wave_sync();
+            }
+        }
+#endif
 
         // ---- epilogue for these F frames, one 16-frame group (= one statistics partial) at a time
         for (int q = 0; q < G; ++q) {

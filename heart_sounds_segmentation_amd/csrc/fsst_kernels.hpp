@@ -486,6 +486,45 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     }
     __syncthreads();
     float* acc = own;
+#ifndef HSS_NO_EXACT
+    // ---- "Exact groups" (fsst_mfma128.hpp): no kept cell of the tile reaches 1e-2 R (R^2 = the bound of the tile's spectrum
+    //      norms: the band holds only the far leakage of something outside it, and float32 resolves ~4e-7 of the frame's
+    //      spectrum norm, not of the band) -> every lane redoes its frame in float64: all one-sided sources, float64 DFT
+    //      of V and Vd', the float64 coordinate rounded half away from zero, the two-sided cyclic scatter into the kept rows.
+    {
+        float mxc = 0.0f;
+        for (int k = 0; k < K; ++k) { const float re = acc[k * LD + tid], im = acc[(K + k) * LD + tid]; mxc = fmaxf(mxc, fmaf(re, re, im * im)); }
+        if (__builtin_amdgcn_ballot_w64(mxc > 1.0e-4f * R2) == 0ull && R2 > 0.0f) {
+            for (int c = 0; c < 2 * K; ++c) acc[c * LD + tid] = 0.0f;
+            const int klo = p.klo;
+            for (int kp = 0; kp <= NWIN / 2; ++kp) {
+                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll 4
+                for (int nn = 0; nn < NWIN; ++nn) {
+                    const double x = static_cast<double>(xs[tid + nn]);
+                    const double2 wd = reinterpret_cast<const double2*>(p.wtab)[nn];
+                    const double2 cs = reinterpret_cast<const double2*>(p.twtab)[(kp * nn) & (NWIN - 1)];
+                    const double xw = x * wd.x, xd = x * wd.y;
+                    vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
+                    dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                }
+                double shift = (dr * vi - di * vr) / (vr * vr + vi * vi);
+                if (!(fabs(shift) <= 1.0e6)) shift = 0.0;           // V == 0 or absurd -> 0 (fsst.m: ~isfinite)
+                const double a = static_cast<double>(kp) + shift;
+                const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
+                const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
+                const double sg = (kp & 1) ? -1.0 : 1.0;              // the modified-STFT phase for even nwin
+                const float re = static_cast<float>(vr * sg), im = static_cast<float>(vi * sg);
+                const int idx = row - klo;
+                if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) { acc[idx * LD + tid] += re; acc[(K + idx) * LD + tid] += im; }
+                if (kp != 0 && kp != NWIN / 2) {                      // the negative-frequency twin N - k' lands in N - row, conjugated
+                    const int idm = ((NWIN - row) & (NWIN - 1)) - klo;
+                    if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) { acc[idm * LD + tid] += re; acc[(K + idm) * LD + tid] -= im; }
+                }
+            }
+        }
+    }
+#endif
 
     const int valid = min(TILE, p.col0 + ncols - t0);
     if (p.mode == kModeRaw) {
