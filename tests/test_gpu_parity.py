@@ -570,18 +570,19 @@ _ADV_KNOWN = {
     (512, "hann", None, "stack", "big dc + tone"), (512, "blackman", None, "stack", "big dc + tone"),
     (512, "kaiser10", None, "stack", "big dc + tone"),
     (512, "flattop", None, "stack", "step"), (512, "flattop", None, "stack", "big dc + tone"),
+    (32, "kaiser10", (300, 450), "stack", "big dc + tone"), (32, "kaiser10", (300, 450), "raw", "big dc + tone"),     # rel-L2 1.10e-4
 }
 
 
-@pytest.mark.parametrize("nwin", [128, 256, 512])
+@pytest.mark.parametrize("nwin", [32, 64, 100, 128, 256, 512])
 @pytest.mark.parametrize("wname", ["kaiser0.5", "hann", "blackman", "kaiser10", "flattop"])
 def test_adversarial_structured_signals(oracle_mod, wname, nwin):
     """The structured sweep of tools/adversarial_parity.py under -m gpu: 10 signals x 3 bands x stack / raw per (window,
     length), the gate of tests/parity.py with no allowance.  What changed since round 2: undecided roundings are a bitmap (no
     queue to overflow: the chirp / tone + noise misses), and a group none of whose stored cells reaches 1e-2 of its own
     spectrum-norm bound is redone in float64 (the empty-band and offset misses).  The canonical band at 128 points passes on
-    every window and signal; _ADV_KNOWN lists the 6 of 900 that are left (the generic kernel of nwin 32 / 64 and the any-length
-    kernel have the bitmap-free tie paths of round 2 and no exact mode: tools/adversarial_parity.py 64 100 lists their misses)."""
+    every window and signal; _ADV_KNOWN lists the 8 of 1 800 that are left.  The generic kernel (nwin 32 / 64) and the any-length
+    kernel (100) redo a quiet tile in float64 the same way; the any-length kernel also when its tie queue overflowed."""
     from scipy.signal import get_window
     fs, names, X = _adversarial_signals()
     spec = {"kaiser0.5": ("kaiser", 0.5), "kaiser10": ("kaiser", 10.0)}.get(wname, wname)
