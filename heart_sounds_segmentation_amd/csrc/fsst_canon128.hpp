@@ -387,6 +387,8 @@ struct CanonParams {
     long long xstride;
     Core128Regions reg;
     unsigned* status;     // FUSED: device status word
+    const unsigned* gate; // non-null: this launch is the fallback of a team-kernel exec: it runs only if *gate == gate_val
+    unsigned gate_val;
 };
 
 constexpr int kCanonCtlFloats = 16 + 192;                            // [0] work counter, [16..207] wide-store offsets
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
     constexpr int ATAB = kCanonAtabFloats;
     constexpr int CTL = FUSED ? kCanonCtlFusedFloats : kCanonCtlFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (p.gate != nullptr && *p.gate != p.gate_val) return;          // (uniform: the team kernel this launch backs up did not give up)
     const int n = p.n;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -423,9 +423,11 @@ __device__ __forceinline__ void store_partial(float* part, float w, float p_re, 
 
 // Per-signal statistics from the partials: one wave per signal.
 // stats[b] = {mean_re, 1/std_re, mean_im, 1/std_im}.
+// (gate != nullptr: the launch is the fallback of a team-kernel exec and runs only if that launch gave up -- *gate == gate_val)
 __global__ __launch_bounds__(64) void fsst_stats_kernel(const float* partials, float4* stats, int nparts, int fpp,
-                                                        int n, int K)
+                                                        int n, int K, const unsigned* gate = nullptr, unsigned gate_val = 0u)
 {
+    if (gate != nullptr && *gate != gate_val) return;
     const long long b = blockIdx.x;
     const float4 st = signal_stats(partials + b * nparts * kPartFloats, nparts, fpp, n, K, threadIdx.x & 63);
     if (threadIdx.x == 0) stats[b] = st;
@@ -577,8 +579,10 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
 // `slices` > 1 cuts every signal into that many contiguous pieces, one block each (small batches: a block per
 // signal would leave most of the chip idle); the fused reduction is only used with slices == 1.
 __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const float4* stats, const float* partials,
-                                                             int nblk, int fpp, int n, int K, int nsignals, int slices)
+                                                             int nblk, int fpp, int n, int K, int nsignals, int slices,
+                                                             const unsigned* gate = nullptr, unsigned gate_val = 0u)
 {
+    if (gate != nullptr && *gate != gate_val) return;    // (see fsst_stats_kernel)
     __shared__ float4 st_sh;
     const int tid = threadIdx.x;
     const int C = 2 * K;

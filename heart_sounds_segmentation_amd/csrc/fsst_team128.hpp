@@ -67,6 +67,9 @@ struct Team128Params {
     unsigned* arrive;     // arrival counter of the plan (monotone over launches)
     unsigned arrive_base; // its value before this launch: block identity = arrival number - arrive_base
     int static_ids;       // development: block identity = blockIdx (teams inside one XCD, but no progress guarantee)
+    unsigned* abort_word; // device word: a wait that ran out of time stores `launch` here; every wave then leaves the kernel
+    unsigned* fallbacks;  // pinned host word: the same store, for the host's eyes (hssfsst_plan_fallbacks)
+    unsigned launch;      // identity of this launch (never 0)
     unsigned long long* probe;   // development (HSS_TEAM_PROBE): per-phase shader-clock totals over all waves
 };
 
@@ -176,16 +179,28 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
 
-    auto gave_up = [&](unsigned code) {
+    // Giving up.  Blocks of a team wait for each other, and nothing guarantees that they are resident together when other
+    // processes use the GPU (workgroups are dealt to the XCDs in order: a launch can stall on a full XCD while the blocks it
+    // did place hold CUs and wait -- tools/team_stress.py with three processes).  So a wait is short (p.spin_ticks, 0.5 ms by
+    // default: a healthy one is microseconds): the wave that runs out of time stores this launch's identity in the abort
+    // word, every wave sees it at its next wait or chunk and leaves, the CUs are free again, and the host has ALREADY queued
+    // the same exec on the two-launch path behind this kernel, gated on that word (hssfsst.hip launch_core128): the features
+    // are then simply computed there.  No error, no result of this kernel is kept.
+    auto aborted = [&]() -> bool {
+        return __hip_atomic_load(p.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.launch;
+    };
+    auto gave_up = [&](unsigned) {
         if (lane == 0) {
-            __hip_atomic_store((gu32*)(p.status), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.abort_word, p.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32*)(p.fallbacks), p.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
-    auto expired = [&]() -> bool {
-        return static_cast<unsigned>(wall_clock64()) - t_start > p.spin_ticks ||
-               __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+    auto expired = [&](unsigned since) -> bool {         // `since` = wall_clock64() when the wait began
+        return static_cast<unsigned>(wall_clock64()) - since > p.spin_ticks ||
+               __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || aborted();
     };
+    if (aborted()) return;                               // (a block that starts after the launch was given up)
 
 #ifdef HSS_TEAM_PROBE
     unsigned long long pr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -287,6 +302,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     // With at most two chunks of a signal per CU (host-checked) a wave never holds three chunks of one signal, which is
     // what rules out waiting for a block sum that only the waiting wave itself could publish.
     for (;;) {
+        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || aborted()) break;     // the launch was given up
         const bool xf = it_valid && !(have_prev && ko - ko_prev >= kTeamWindow);
         long long b = 0;
         int grp0 = 0, ngrp = 0, ko_cur = 0;
@@ -299,13 +315,14 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         if (xf) {
             PROBE(7);
             // ---- window: do not start a chunk kTeamWindow signals ahead of the oldest unresolved signal of a sibling
+            const unsigned tw_window = static_cast<unsigned>(wall_clock64());
             for (;;) {
                 int fl = 0x7fffffff;
                 if (lane < kTeamWaves && lane != wv) fl = __hip_atomic_load(pend + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                 for (int off = 1; off < kTeamWaves; off <<= 1) fl = min(fl, __shfl_xor(fl, off));
                 if (ko - __builtin_amdgcn_readfirstlane(fl) < kTeamWindow) break;
-                if (expired()) { gave_up(4u); break; }
+                if (expired(tw_window)) { gave_up(4u); break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             PROBE(0);
@@ -521,6 +538,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
             PROBE(7);
             // mailbox passes with ALL loads of a pass in flight at once: under load a mailbox read is a 2-3 us trip through
             // this CU's own memory queue (MI355X_MICROARCH.md, handoff-1to1)
+            const unsigned tw_mail = static_cast<unsigned>(wall_clock64());
             while (!done) {
                 bool ok = true;
                 acc = 0.0;
@@ -544,7 +562,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 break;
 #endif
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                if (expired()) { gave_up(3u); break; }
+                if (expired(tw_mail)) { gave_up(3u); break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             PROBE(3);

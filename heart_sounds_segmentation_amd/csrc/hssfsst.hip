@@ -166,7 +166,11 @@ struct hssfsst_plan {
     volatile unsigned* h_status = nullptr;                   // ... and the same word in pinned host memory: read without a sync
     unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][chunks][8] (8-byte words)
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
-    unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: arrival counter and its value after the launches so far
+    unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word
+    unsigned team_launch = 0;                                // identity of the last team launch (never 0)
+    volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
+    unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
+    const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
     int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
     int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
     int zpath_pref = 0;                                      // HSSFSST_ZPATH_*: preference among the z-score paths
@@ -368,11 +372,28 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
     if (CANON) { tp.atab = pl->d_atab16; tp.r2scale = pl->canon_r2s; tp.inv_c = pl->canon_inv_c; }
     tp.n = cp.n; tp.klo = cp.klo; tp.K = cp.K; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
     tp.team = T; tp.cpc = cpc; tp.cpc_shift = cpc_shift; tp.nchunks = NC; tp.seq = pl->team_seq;
-    tp.spin_ticks = 200u * 1000u * 1000u;                // 2 s of the 100 MHz counter
+    // how long a wave waits for its team before the launch is given up (microseconds of the 100 MHz counter; a healthy wait
+    // is a few microseconds, a team-mate in the float64 passes can take hundreds)
+    static const unsigned spin_us = std::getenv("HSSFSST_TEAM_SPIN_US") ? static_cast<unsigned>(std::atoi(std::getenv("HSSFSST_TEAM_SPIN_US"))) : 500u;
+    tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
     if (!pl->d_arrive) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), sizeof(unsigned)));
-        HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, sizeof(unsigned), st));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 2 * sizeof(unsigned), st));
         pl->arrive_total = 0;
+        void* h = nullptr;
+        HIP_TRY(hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
+        *static_cast<volatile unsigned*>(h) = 0u;
+        void* d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+        pl->h_fallback = static_cast<volatile unsigned*>(h);
+        pl->d_fallback = static_cast<unsigned*>(d);
+    }
+    if (++pl->team_launch == 0u) pl->team_launch = 1u;
+    tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
+    static const bool force_fallback = std::getenv("HSSFSST_TEAM_FORCE_FALLBACK") != nullptr;   // tests: every team launch finds itself given up
+    if (force_fallback) {
+        HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
     }
     static const bool static_ids = std::getenv("HSSFSST_TEAM_STATIC") != nullptr;  // A/B: teams inside one XCD, no progress guarantee
     tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total; tp.static_ids = static_ids ? 1 : 0;
@@ -417,6 +438,7 @@ hssfsst::CanonParams canon_params(const hssfsst_plan* pl, const hssfsst::Core128
     q.r2scale_s = pl->canon_r2s; q.inv_c = pl->canon_inv_c;
     q.n = cp.n; q.mode = cp.mode; q.nsig = cp.nsig; q.col0 = cp.col0; q.ncols = cp.ncols; q.xstride = cp.xstride; q.reg = cp.reg;
     q.status = cp.status;
+    q.gate = pl->gate; q.gate_val = pl->gate_val;
     return q;
 }
 
@@ -510,7 +532,17 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         // (the team kernel exists for the canonical band only -- fsst_canon128.hpp; other bands: one CU per signal or two launches)
         if (rc == 0 && !no_team && canon16 && (col0 & 63) == 0) {
             rc = launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st);
-            if (rc == 1) { *did_fuse = true; pl->last_zpath = 2; return 0; }
+            if (rc == 1) {
+                // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
+                // them apart: fsst_team128.hpp "Giving up"): the same exec is queued behind it on the two-launch path, every
+                // kernel of it gated on the abort word -- a few microseconds of empty launches when nothing went wrong
+                pl->last_zpath = 2;
+                pl->gate = pl->d_arrive + 1; pl->gate_val = pl->team_launch;
+                const int rc2 = launch_canon(pl, cp, nchunks, st);
+                if (rc2 != 0) { pl->gate = nullptr; return rc2; }
+                *did_fuse = false;                       // (exec_impl adds the gated statistics + z-score launches)
+                return 0;
+            }
         }
         if (rc < 0) return rc;
         if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
@@ -803,6 +835,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
     if (p->d_arrive) (void)hipFree(p->d_arrive);
+    if (p->h_fallback) (void)hipHostFree(const_cast<unsigned*>(p->h_fallback));
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
@@ -831,6 +864,16 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
 
 
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? p->last_zpath : 0; }
+
+int hssfsst_plan_fallbacks(hssfsst_plan* p)
+{
+    if (!p) return fail(HSSFSST_EINVAL, "plan_fallbacks: plan is NULL");
+    if (p->h_fallback) {
+        const unsigned now = *p->h_fallback;
+        if (now != p->seen_fallback) { p->seen_fallback = now; ++p->fallbacks; }
+    }
+    return p->fallbacks;
+}
 
 int hssfsst_plan_set_zpath(hssfsst_plan* p, int zpath)
 {
@@ -1073,7 +1116,10 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         }
         if (rc != 0) return rc;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
-        p->last_fused = did_fuse ? 1 : 0;
+        const unsigned* gate = p->gate;                  // non-null: a team launch went first; what follows is its gated fallback
+        const unsigned gate_val = p->gate_val;
+        p->gate = nullptr;
+        p->last_fused = (did_fuse || gate != nullptr) ? 1 : 0;
         if (p->mode == HSSFSST_MODE_STACK && !did_fuse) {
             hipStream_t zs = st;
             if (piped) {
@@ -1101,9 +1147,10 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             const bool fused = !split_stats && slices == 1 && zgrid == cb && cb >= 512;
             if (!fused)
                 hipLaunchKernelGGL(hssfsst::fsst_stats_kernel, dim3(static_cast<unsigned>(cb)), dim3(64), 0, zs,
-                                   cp.partials, cstats, nblk, fpp, ncols, p->K);
+                                   cp.partials, cstats, nblk, fpp, ncols, p->K, gate, gate_val);
             hipLaunchKernelGGL(hssfsst::fsst_normalize_kernel, dim3(static_cast<unsigned>(zgrid)), dim3(256), 0, zs,
-                               cout, cstats, fused ? cp.partials : nullptr, nblk, fpp, ncols, p->K, static_cast<int>(cb), slices);
+                               cout, cstats, fused ? cp.partials : nullptr, nblk, fpp, ncols, p->K, static_cast<int>(cb), slices,
+                               gate, gate_val);
             HIP_TRY(hipGetLastError());
         }
     }

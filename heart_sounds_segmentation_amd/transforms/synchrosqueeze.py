@@ -277,6 +277,13 @@ class FSST:
         code = {"auto": 0, "two_launch": 1, "one_cu": 2, "team": 3}[zpath]
         _lib.check(_lib.lib().hssfsst_plan_set_zpath(self._plan(dev).handle, code), "hssfsst_plan_set_zpath")
 
+    def fallbacks(self, device_index: Optional[int] = None) -> int:
+        """Extension: how many team-kernel launches of that device's plan gave themselves up and were computed by the
+        two-launch kernels queued behind them (other processes kept the team's blocks apart): a performance event, not
+        an error.  Call after a synchronisation."""
+        dev = self._device_index() if device_index is None else device_index
+        return int(_lib.lib().hssfsst_plan_fallbacks(self._plan(dev).handle))
+
     def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
         """Extension (bench): record HIP events around the kernels of every following call."""
         dev = self._device_index() if device_index is None else device_index

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 205
+#define HSSFSST_VERSION 206
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -98,9 +98,9 @@ int hssfsst_exec_list(hssfsst_plan* plan, const float* x, int64_t x_len, const i
                       int64_t batch, int n, int x_on_device, float* out, int out_on_device, void* stream);
 
 /* Device-side health of the plan's asynchronous work.  The single-launch z-score kernels contain waits on other
- * waves (of the same CU: the one-CU-per-signal kernel; of other CUs of a team: the team kernel, which needs all its
- * blocks resident at once -- the library sizes its grid to the CUs of the device).  Every such wait is bounded (2 s) and
- * a give-up is recorded in a status word in pinned host memory instead of hanging the GPU.  The library looks at that
+ * waves (of the same CU: the one-CU-per-signal kernel; of other CUs of a team: the team kernel, see hssfsst_plan_fallbacks).
+ * Every wait of the one-CU-per-signal kernel is bounded (2 s) and a give-up is recorded in a status word in pinned host
+ * memory instead of hanging the GPU.  The library looks at that
  * word without synchronising at the start of EVERY exec of the plan and returns HSSFSST_EHIP if an earlier exec's wait
  * gave up (that exec's features are invalid), so a caller of device-output execs learns of it at the next call at the
  * latest; host-output execs check before they return; this function waits for the device and checks now. */
@@ -120,6 +120,12 @@ int hssfsst_plan_last_exec_fused(const hssfsst_plan* plan);
 #define HSSFSST_ZPATH_ONE_CU 2
 #define HSSFSST_ZPATH_TEAM 3
 int hssfsst_plan_set_zpath(hssfsst_plan* plan, int zpath);
+
+/* The team kernel's blocks wait for each other; when they are kept apart (other processes' kernels on the same GPU) a wait
+ * runs out of time (0.5 ms), the launch gives itself up and the exec is computed by the two-launch kernels that the library
+ * queues behind every team launch, gated on exactly that event: same result, no error.  This returns how many distinct team
+ * launches of the plan were seen to have fallen back so far (sampled whenever it is called: call it after a synchronisation). */
+int hssfsst_plan_fallbacks(hssfsst_plan* plan);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in

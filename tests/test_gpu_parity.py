@@ -4,6 +4,8 @@ golden fixtures, and -- at BASELINE.json's full C2 size -- through size-independ
 Nothing here reads /root/reference."""
 import ctypes
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -630,6 +632,39 @@ def test_zpath_preference_is_bit_identical(batch):
             assert torch.equal(got, ref), zp
     with pytest.raises(KeyError):
         tf.set_zpath("fastest")
+
+
+_FALLBACK_CHILD = r"""
+import sys, torch
+from heart_sounds_segmentation_amd import FSST, synth
+w = synth.kaiser_window(128, 0.5)
+X = torch.from_numpy(synth.pcg_windows(40, 2000, seed=5)).cuda()
+tf = FSST(1000, w, truncate_freq=(25, 200), stack=True)
+got = tf.batch(X)
+path = tf.check()
+print("PATH", path, "FALLBACKS", tf.fallbacks())
+torch.save(got.cpu(), sys.argv[1])
+"""
+
+
+def test_team_kernel_fallback_and_other_processes(tmp_path):
+    """The team kernel's blocks wait for each other; kept apart (other processes on the GPU) a wait runs out of time, the
+    launch gives itself up and the two-launch kernels queued behind it, gated on that event, compute the exec: same bits,
+    no error.  (1) forced: HSSFSST_TEAM_FORCE_FALLBACK=1 makes every team launch find itself given up; (2) for real: three
+    processes hammering one GPU with small batches (tools/team_stress.py; with block identities = blockIdx and the 2 s
+    wait of the first version this raised in every process)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("plain", {}), ("forced", {"HSSFSST_TEAM_FORCE_FALLBACK": "1"}), ("two", {"HSSFSST_NO_FUSED": "1"})):
+        f = str(tmp_path / f"{name}.pt")
+        r = subprocess.run([sys.executable, "-c", _FALLBACK_CHILD, f], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs[name] = (torch.load(f), r.stdout)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert "PATH 2 FALLBACKS 0" in outs["plain"][1] and "PATH 2 FALLBACKS 1" in outs["forced"][1] and "PATH 0" in outs["two"][1], [o[1] for o in outs.values()]
+    assert torch.equal(outs["plain"][0], outs["forced"][0]) and torch.equal(outs["plain"][0], outs["two"][0])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "team_stress.py"), "3", "200"], cwd=root, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "exit codes [0, 0, 0]" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
 
 
 def test_corpus_builder_and_end_to_end(oracle_mod):
