@@ -459,6 +459,9 @@ int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nch
     }
     int64_t blocks = nchunks;
     if (blocks > pl->canon_slots) blocks = pl->canon_slots;
+    // (a gated launch -- the fallback behind a team launch -- almost always finds its gate closed: a quarter of the chip keeps
+    //  the empty launch at ~2 us instead of ~4; when it does run, the GPU is shared anyway)
+    if (pl->gate != nullptr && blocks > 64) blocks = 64;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
     HIP_TRY(hipGetLastError());
     return 0;
