@@ -32,7 +32,8 @@ using lds_u4 = __attribute__((address_space(3))) u4;
 
 constexpr int kCanonTileFrames = 64;                     // frames per aligned tile (4 groups = one statistics block)
 constexpr int kCanonRecs = 192;                          // sample records per tile: 64 + 127, rounded up
-constexpr int kCanonAtabFloats = 16 * 64 * 4;            // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
+constexpr int kCanonOpFloats = 16 * 64 * 4;              // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
+constexpr int kCanonAtabFloats = kCanonOpFloats + 4 * 128;   // + {cos, sin}(2 pi m / 128) as float64 (rounding-tie path), 2 kB
 constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
 // (rounding ties: the bitmap of fsst_mfma128.hpp, "Rounding ties"; the float64 path reads the signal's own samples)
 constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
@@ -156,11 +157,20 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
 template <int KLO, int KC, int TAPB = 4>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
-                                            const float* xsig, int n, int tg)
+                                            const float* xsig, int n, int tg, unsigned long long* cp = nullptr)
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
+#ifdef HSS_CANON_PROBE                                   // development: issue-time stamps at the phase boundaries of a group
+    unsigned long long cp_last = __builtin_readcyclecounter();
+#define CPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); \
+                       if (cp) cp[k] += now_ - cp_last; cp_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPROBE(k) do { } while (0)
+#endif
     const int g = lane_o >> 4, j = lane_o & 15;
+    const double* tw_lds = reinterpret_cast<const double*>(atab + kCanonOpFloats);   // the twiddles' copy in LDS (twtab: in HBM)
+    (void)twtab;
     // lane (kk = g, f = j) is row-block kk of the B operand for frame f: records f + tap + 16 kk and + 64 (fold terms kk, kk + 4:
     // the 32 lanes of a half-wave then read 32 consecutive records -- every LDS bank once; with terms 2 kk, 2 kk + 1 the two
     // lane groups of a half-wave were 256 bytes apart, on the same banks)
@@ -202,10 +212,12 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         });
         __builtin_amdgcn_sched_barrier(0);
     });
+    CPROBE(0);
 #if !defined(HSS_CANON_ABLATE) || HSS_CANON_ABLATE < 5
     fft_n<NT>(za);
     fft_n<NT>(zb);
 #endif
+    CPROBE(1);
 
     // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
     unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
@@ -246,6 +258,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
             if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, cellB, STB);
         }
     });
+    CPROBE(2);
     wave_sync();
     int f_dirty = flag[0], f_ties = flag[1];             // one LDS round trip for both per-group flags (the empty statement keeps
     asm volatile("" : "+v"(f_dirty), "+v"(f_ties));      // the compiler from sinking the second read behind the first branch)
@@ -275,15 +288,15 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
         if (lane_o < 2) flag[lane_o] = 0;
         wave_sync();
-        resolve_bitmap<NWIN, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD,
-                                   C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        resolve_bitmap<NWIN, true, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD,
+                                         C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
     } else
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(f_ties) != 0, 0)) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
         // 1e-5 bins from a half-integer needs all 24
-        resolve_bitmap<NWIN>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, twtab, 1.0 / static_cast<double>(tile.inv), lane_o);
+        resolve_bitmap<NWIN, false, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
     }
@@ -296,6 +309,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         if (lane_o == 0) *flag = 0;
         wave_sync();
     }
+    CPROBE(3);
+#undef CPROBE
 }
 
 // Statistics partial of the group in the own plane (see "Statistics" in fsst_kernels.hpp): pivoted sums over the kept cells

@@ -391,7 +391,100 @@ __device__ __forceinline__ void resolve_one(f2* disp_base, int LDF, int* flag, i
 // frames, rewrites the own cell with the float64 value, rounds the float64 coordinate, moves.  ~50x the cost of the group;
 // ordinary signals never get there (white noise: largest cell 0.09 R).
 constexpr float kExactTheta2 = 1.0e-4f;      // (1e-2)^2
-template <int NWIN, bool REFRESH = false, class Sample>
+__device__ __forceinline__ double readlane_f64(double v, int l)      // lane l's value in every lane (l wave-uniform)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b), l));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b >> 32), l));
+    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+// TWLDS: `twtab` points into LDS (the canonical-band kernels keep the 2 kB of twiddles beside their operand table).
+using d2v = double __attribute__((ext_vector_type(2)));
+using lds_d2v = __attribute__((address_space(3))) d2v;
+template <bool TWLDS>
+__device__ __forceinline__ d2v tie_twiddle(const double* twtab, int idx)
+{
+    if constexpr (TWLDS) return ((const lds_d2v*)reinterpret_cast<const d2v*>(twtab))[idx];
+    else return reinterpret_cast<const d2v*>(twtab)[idx];
+}
+// Heavily undecided groups at nwin = 128 (an on-bin tone under a near-rectangular window, a band that holds only leakage:
+// ~1000 of the group's 1024 (source, frame) cells).  One float64 DFT per cell is 128 taps x 4 FMAs; done for all cells it is the
+// fold + 16-point DFT factorisation of the float32 kernel in float64 instead: per tap ONE pair of v_mfma_f64_16x16x4_f64
+// gives lane (g, j) the folded {Za, Zb}[tap] of its two classes for frame j (A operand: the float64 table a64 behind the
+// twiddles of `wtab`, made by the host with the row order of the float64 instruction; B operand: the float32 samples, exact
+// in float64), and the lane accumulates the 16-point DFT outputs of ONE stripe at a time (8 passes: registers) -- X = Z[8 s + r]
+// and its conjugate partner, as process_stripe.  16 complex multiply-adds per cell instead of 128 real-complex ones.
+// Measured on an on-bin tone (every group): 22.8 -> 2.9 ms per 1024 windows, 1.0 of it the displaced cells themselves.  The
+// fold is redone in every pass (64 cycles per float64 matrix instruction on this chip: ~40 % of the path); holding its 16 x 4
+// doubles per lane would take 128 registers, two stripes per pass made the 128-register kernels spill, and making the A
+// operand on the spot from the window pair and twiddles in LDS instead of loading it was slower (4.3 ms).
+// sample(i): sample i of the group's first frame.
+constexpr int kFold64Doubles = 16 * 2 * 64;
+__device__ __forceinline__ d2v uniform_d2v(d2v v)
+{
+    auto u = [](double x) -> double {
+        const long long b = __double_as_longlong(x);
+        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b)));
+        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32)));
+        return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+    };
+    return d2v{u(v.x), u(v.y)};
+}
+using d4v = double __attribute__((ext_vector_type(4)));
+template <bool REFRESH, bool TWLDS, class Sample>
+__device__ __forceinline__ void resolve_group_f64(const unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                                  f2* own_base, int OLD, int cov0, int cov1, const double* a64, const double* twtab,
+                                                  double plane_scale, int lane)
+{
+    constexpr int NWIN = 128, NT = 16, RQ = 8;
+    const int g = lane >> 4, j = lane & 15;
+    const bool isg0 = g == 0;
+    const int rA = g, rB = isg0 ? RQ / 2 : RQ - g;
+    float xs[2][NT];                                     // B operand rows kk = g and g + 4 of every tap: x[j + n + 16 kk]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xs[h][n] = static_cast<float>(sample(j + n + 16 * (g + 4 * h)));
+    // this lane's flagged frames: bit (k' & 1) * 16 + j of word k' >> 1
+    auto flagged = [&](int kp) -> bool { return REFRESH || ((tb[kp >> 1] >> (((kp & 1) << 4) + j)) & 1u) != 0u; };
+    auto cmac = [](double& ar, double& ai, double zr, double zi, d2v cs) {      // a += z (cos - i sin)
+        ar = fma(zr, cs.x, ar); ar = fma(zi, cs.y, ar);
+        ai = fma(zi, cs.x, ai); ai = fma(-zr, cs.y, ai);
+    };
+#pragma unroll 1
+    for (int s = 0; s < NT / 2; ++s) {                   // (one stripe per pass: 16 accumulator registers; two made the 128-register kernels spill)
+        double xa[2] = {0.0, 0.0}, xb[2] = {0.0, 0.0}, pza[2] = {0.0, 0.0}, pzb[2] = {0.0, 0.0};
+        const int ia = isg0 ? ((NT - s) & (NT - 1)) : NT - 1 - s;                // partner index in array a (process_stripe)
+#pragma unroll 2
+        for (int n = 0; n < NT; ++n) {
+            const double a0 = a64[(2 * n) * 64 + lane], a1 = a64[(2 * n + 1) * 64 + lane];
+            d4v z = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, static_cast<double>(xs[0][n]), d4v{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, static_cast<double>(xs[1][n]), z, 0, 0, 0);
+            // (t1, t2 are the same in every lane: scalar registers -- eight vector registers the 128-register kernels lack)
+            const d2v t1 = uniform_d2v(tie_twiddle<TWLDS>(twtab, (RQ * s * n) & (NWIN - 1)));
+            const d2v t2 = uniform_d2v(tie_twiddle<TWLDS>(twtab, (RQ * (NT - 1 - s) * n) & (NWIN - 1)));
+            const d2v t3 = tie_twiddle<TWLDS>(twtab, (RQ * ia * n) & (NWIN - 1));
+            cmac(xa[0], xa[1], z.x, z.y, t1);
+            cmac(xb[0], xb[1], z.z, z.w, t1);
+            cmac(pzb[0], pzb[1], z.z, z.w, t2);
+            cmac(pza[0], pza[1], z.x, z.y, t3);
+        }
+        const double par = isg0 ? pza[0] : pzb[0], pai = isg0 ? pza[1] : pzb[1];      // partner of source a
+        const double pbr = isg0 ? pzb[0] : pza[0], pbi = isg0 ? pzb[1] : pza[1];      // partner of source b
+        const int ka = RQ * s + rA, kb = RQ * s + rB;
+        // plane values (-1)^k' V = X + conj(P), (-1)^k' Vd' = (X - conj(P)) / i; resolve_one takes V, Vd' themselves
+        const double sa = (ka & 1) ? -1.0 : 1.0, sb = (kb & 1) ? -1.0 : 1.0;
+        if (flagged(ka))
+            resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, ka, j,
+                                       sa * (xa[0] + par), sa * (xa[1] - pai), sa * (xa[1] + pai), sa * (par - xa[0]), plane_scale);
+        if (flagged(kb))
+            resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kb, j,
+                                       sb * (xb[0] + pbr), sb * (xb[1] - pbi), sb * (xb[1] + pbi), sb * (pbr - xb[0]), plane_scale);
+    }
+}
+
+constexpr int kTieGroup64 = 24;              // nwin = 128: from this many undecided cells on the group is redone by resolve_group_f64
+template <int NWIN, bool REFRESH = false, bool TWLDS = false, class Sample>
 __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
                                                f2* own_base, int OLD, int cov0, int cov1,
                                                const double* wtab, const double* twtab, double plane_scale, int lane_in)
@@ -410,6 +503,14 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
         for (int b = 0; b < 6; ++b) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((cnt >> b) & 1)) << b;
         if constexpr (REFRESH) total = 1024;
         if (total == 0) continue;
+        if constexpr (NWIN == 128) {
+            if (total >= kTieGroup64) {
+                resolve_group_f64<REFRESH, TWLDS>(tbs, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, wtab + 4 * NWIN, twtab,
+                                                  plane_scale, lane);
+                if (lane < 32) tbs[lane] = 0u;
+                continue;
+            }
+        }
         if (total <= kTieCoop) {
             // few cells: one by one, all lanes on one cell (NWIN / 64 taps per lane, float64 butterfly sum)
             for (int it = 0; it < total; ++it) {
@@ -424,7 +525,7 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
                 for (int n = lane; n < NWIN; n += 64) {
                     const double x = sample(jf + n);
                     const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-                    const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
+                    const d2v cs = tie_twiddle<TWLDS>(twtab, (kpi * n) & (NWIN - 1));
                     const double xw = x * wd.x, xd = x * wd.y;
                     vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
                     dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
@@ -437,26 +538,43 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
                 if (lane == 0) resolve_one<NWIN>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
             }
         } else {
-            // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = k0 + l and
-            // walks the frames whose bit is set -- at most 16 rounds, every round a full float64 DFT per lane (the window
-            // pair: one address for the wave; the twiddle: per lane from the 16 nwin byte table)
-            unsigned hw = REFRESH ? 0xffffu : (tbs[lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
+            // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = k0 + l, and
+            // the wave walks the FRAMES that have a bit set in some lane.  One frame per round: its windowed samples x w,
+            // x dw' are the same for every source, so each lane computes NWIN / 64 of them (coalesced loads) and the round
+            // hands them round through v_readlane; per tap a lane then loads only its twiddle (the 16 nwin byte table, L1 /
+            // L2).  Same products, same order of additions as the one-by-one branch above.  (The first version let every
+            // lane walk its own frames -- three dependent-latency loads per tap and lane: 730 cycles per tap, 23 ms per
+            // 1024 windows of an on-bin tone; profiles/r03_input_cost.txt.)
+            const unsigned hw = REFRESH ? 0xffffu : (tbs[lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
             const int kpi = k0 + lane;
-            while (__builtin_amdgcn_ballot_w64(hw != 0u) != 0ull) {
-                const bool act = hw != 0u;
-                const int jf = act ? __builtin_ctz(hw) : 0;
-                hw &= hw - 1u;
-                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 4
-                for (int n = 0; n < NWIN; ++n) {                 // (unrolled: four table / sample loads in flight; not unrolled
-                    const double x = sample(jf + n);             //  every tap waits out a full memory latency: 80x on nwin 512)
+            unsigned fm = 0u;                                    // frames with work (wave-uniform)
+#pragma unroll
+            for (int b = 0; b < 16; ++b) fm |= (__builtin_amdgcn_ballot_w64((hw >> b) & 1u) != 0ull ? 1u : 0u) << b;
+            while (fm != 0u) {
+                const int jf = __builtin_ctz(fm);
+                fm &= fm - 1u;
+                constexpr int TPL = NWIN / 64;                   // taps per lane
+                double xw[TPL], xd[TPL];
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) {
+                    const int n = lane + 64 * t;
+                    const double x = sample(jf + n);
                     const double2 wd = reinterpret_cast<const double2*>(wtab)[n];
-                    const double2 cs = reinterpret_cast<const double2*>(twtab)[(kpi * n) & (NWIN - 1)];
-                    const double xw = x * wd.x, xd = x * wd.y;
-                    vr = fma(xw, cs.x, vr); vi = fma(-xw, cs.y, vi);
-                    dr = fma(xd, cs.x, dr); di = fma(-xd, cs.y, di);
+                    xw[t] = x * wd.x; xd[t] = x * wd.y;
                 }
-                if (act) resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
+                double vr = 0.0, vi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) {
+#pragma unroll 8
+                    for (int l = 0; l < 64; ++l) {
+                        const int n = 64 * t + l;
+                        const double a = readlane_f64(xw[t], l), b = readlane_f64(xd[t], l);
+                        const d2v cs = tie_twiddle<TWLDS>(twtab, (kpi * n) & (NWIN - 1));
+                        vr = fma(a, cs.x, vr); vi = fma(-a, cs.y, vi);
+                        dr = fma(b, cs.x, dr); di = fma(-b, cs.y, di);
+                    }
+                }
+                if ((hw >> jf) & 1u) resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
             }
         }
         if (lane < 32) tbs[lane] = 0u;
@@ -555,10 +673,13 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
 template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false>
 __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
 {
-    static_assert(!FUSED || FAST, "the fused z-score rides on the wide-store epilogue");
+    // (FUSED && !FAST: the general epilogue's STACK mode -- any K, nwin 256 / 512 -- with the linear z-score sweep of
+    //  fsst_normalize_kernel as the B ticket; the host sends only STACK execs whose signal blocks are 16-byte aligned)
     constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
     constexpr int ATAB = core128_atab_floats(RQ, NT);
-    constexpr int CTL = FUSED ? kCtlFusedFloats : kCtlFloats;
+    // (FUSED && !FAST: the plain control block -- the statistics partials stay in HBM as on the two-launch path, the wave
+    //  regions of nwin 256 / 512 leave no LDS for them --, resolved statistics at [16..31])
+    constexpr int CTL = (FUSED && FAST) ? kCtlFusedFloats : kCtlFloats;
     constexpr int XS = ((FPW + NWIN - 1 + 3) / 4) * 4;
     using avec = float __attribute__((ext_vector_type(KST)));          // one tap's A operand, all k-steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -578,7 +699,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     unsigned* done_a = reinterpret_cast<unsigned*>(smem + ATAB) + 1;         // FUSED: [2] groups delivered (monotone)
     unsigned* dead = done_a + 2;                                             // FUSED: a wait of this block gave up
     unsigned* ready = dead + 1;                                              // FUSED: [4] epoch of fin_stats[]
-    float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + 272);        // FUSED: [4] resolved statistics
+    float4* fin_stats = reinterpret_cast<float4*>(smem + ATAB + (FAST ? 272 : 16));   // FUSED: [4] resolved statistics
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // FUSED: [64] see "cls" below
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + (FUSED ? 80 : 16));   // [3][64] wide-store offsets (FAST)
     float* part_lds = smem + ATAB + 288;                                     // FUSED: [2][kFusedMaxGroups][kPartFloats]
@@ -600,7 +721,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     if (lane < 4) flag[lane] = 0;
     for (int i = lane; i < tie_words(NWIN); i += 64) tq[i] = 0;
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
-    if constexpr (FUSED) {
+    if constexpr (FUSED && FAST) {
         if (wv == 0) {
             // bit 2i / 2i+1 of cls: the first / second pair of this lane's float4 i (of a group's [16][2K] image) is an
             // imaginary column
@@ -742,6 +863,45 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const float4 st = fin_stats[sl];
+        if constexpr (!FAST) {
+            // general K: the chunk's frames x 2K floats are one contiguous, 16-byte aligned run of `out`; float4 sweep with
+            // the column tracked incrementally and a per-element wrap test, the arithmetic of fsst_normalize_kernel
+            // (kZB float4 per lane in flight at a time: one memory round trip per 64 kZB float4)
+            constexpr int kZB = 12;
+            const int frames = min(ngrp * 16, ncols - grp0 * 16);
+            const int nfl = frames * C;                      // even
+            const int nf4 = nfl >> 2;
+            f4* b4 = reinterpret_cast<f4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * C);
+            int c = static_cast<int>((4u * static_cast<unsigned>(lane_o)) % static_cast<unsigned>(C));
+            const int dc = static_cast<int>(256u % static_cast<unsigned>(C));
+            auto zs1 = [&](float v, int col) -> float { return (col < K) ? (v - st.x) * st.y : (v - st.z) * st.w; };
+            for (int i0 = 0; i0 < nf4; i0 += 64 * kZB) {
+                f4 o[kZB];
+#pragma unroll
+                for (int u = 0; u < kZB; ++u) {
+                    const int idx = i0 + 64 * u + lane_o;
+                    o[u] = __builtin_nontemporal_load(b4 + (idx < nf4 ? idx : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < kZB; ++u) {
+                    const int idx = i0 + 64 * u + lane_o;
+                    int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+                    if (c1 >= C) c1 -= C;
+                    if (c2 >= C) c2 -= C;
+                    if (c3 >= C) c3 -= C;
+                    const f4 r = {zs1(o[u].x, c), zs1(o[u].y, c1), zs1(o[u].z, c2), zs1(o[u].w, c3)};
+                    if (idx < nf4) __builtin_nontemporal_store(r, b4 + idx);
+                    c += dc;
+                    if (c >= C) c -= C;
+                }
+            }
+            if ((nfl & 2) && lane_o == 0) {                  // frames x 2K = 2 mod 4: the last two floats of the chunk
+                float* tl = p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * C + (nfl - 2);
+                const int ct = C - 2;                        // (they end a row)
+                tl[0] = zs1(tl[0], ct);
+                tl[1] = zs1(tl[1], ct + 1);
+            }
+        } else {
         const unsigned cls = cls_lds[lane_o];
         // One memory round trip per ticket: all 12 pieces (4 groups x 3 float4) of the chunk in flight at once.  The loads
         // are unconditional (a lane without a piece re-reads the chunk's first float4): conditionally defined registers
@@ -783,6 +943,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
                     }
                 }
             }
+        }
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
@@ -1043,7 +1204,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             }
             if (p.mode == kModeStack) {
                 const float w = piece_sums(st_s.x, st_q.x, st_s.y, st_q.y);
-                store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
+                store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);     // (FUSED too: see CTL)
             }
         }
         wave_sync();
@@ -1065,7 +1226,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             int ncols_o = ncols, K_o = K, ng_o = ngroups;    // opaque: nothing of the float64 arithmetic below may be
             asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(ng_o));   // hoisted out of the work loop (it would be spilled)
-            const float4 st = signal_stats(part_lds + sl * kFusedMaxGroups * kPartFloats, ng_o, 16, ncols_o, K_o, lane_o);
+            // (!FAST: the partials were written to HBM by waves of this workgroup, each wave's stores complete before its
+            //  release on the delivery counter, and no line of them was read by this CU before)
+            const float* parts = FAST ? part_lds + sl * kFusedMaxGroups * kPartFloats : p.partials + b * ngroups * kPartFloats;
+            const float4 st = signal_stats(parts, ng_o, 16, ncols_o, K_o, lane_o);
             if (lane == 0) {
                 fin_stats[static_cast<int>(ksig) & 3] = st;
                 __hip_atomic_store(ready + (static_cast<int>(ksig) & 3), static_cast<unsigned>(ksig) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

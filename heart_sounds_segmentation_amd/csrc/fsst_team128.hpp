@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
 
 #ifdef HSS_TEAM_PROBE
     unsigned long long pr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pr_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // per-group phases of the transform (HSS_CANON_PROBE)
     unsigned long long pr_last = __builtin_readcyclecounter();
     const unsigned long long pr_begin = pr_last;
 #define PROBE(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); pr_t[k] += now_ - pr_last; pr_last = now_; } while (0)
@@ -362,7 +363,16 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 const int tg = t0 + grp * 16;
                 if constexpr (CANON) {
                     canon_group<KLO, KC, 2>(reinterpret_cast<const u2*>(xs) + grp * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab,
-                                         tile, tiny, lane_o, p.x + b * p.xstride, n, tg);
+                                         tile, tiny, lane_o, p.x + b * p.xstride, n, tg
+#ifdef HSS_TEAM_PROBE
+                                         , pr_c
+#endif
+                                         );
+#ifdef HSS_TEAM_PROBE
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned long long pc_last = __builtin_readcyclecounter();
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                     const int nvalid = min(16, cend - tg);
                     f2 piv;
                     const float w = canon_stats<KLO, KC>(own_base, nvalid, tile.inv, lane_o, piv);
@@ -372,6 +382,9 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                     const float pf32 = (q & 2) ? piv.y : piv.x;
                     const double cnt = static_cast<double>(nvalid) * static_cast<double>(K);
                     bsum += piece_moment(q, static_cast<double>(s1f), static_cast<double>(s2f), static_cast<double>(pf32), cnt);
+#ifdef HSS_TEAM_PROBE
+                    { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); pr_c[4] += now_ - pc_last; pc_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#endif
                     // the group index is wave-uniform: a four-way branch around the 12 LDS reads of the image, each arm
                     // writing its own float4 registers (no M0-indexed moves, no 16-register tuples to keep aligned)
                     static_for<kTeamGpc>([&](auto G) {
@@ -379,6 +392,9 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                         if (grp == gq) canon_image_to<KLO, KC>(own_base, ppk_lds, tile.inv, lane_o, [&](int i, f4 v) { curq[i][gq] = v; });
                     });
                     wave_sync();
+#ifdef HSS_TEAM_PROBE
+                    { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); pr_c[5] += now_ - pc_last; __builtin_amdgcn_sched_barrier(0); }
+#endif
                     continue;
                 }
                 unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)(xs + grp * 16 + j + NT * g)));
@@ -646,6 +662,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     if (lane == 0) {
         pr_t[6] = __builtin_readcyclecounter() - pr_begin;
         for (int k = 0; k < 8; ++k) atomicAdd(p.probe + k, pr_t[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(p.probe + 16 + k, pr_c[k]);
         atomicAdd(p.probe + 8, 1ull);
     }
 #endif

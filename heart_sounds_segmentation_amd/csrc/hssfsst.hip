@@ -303,6 +303,36 @@ int launch_fused128(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, 
     return 1;
 }
 
+// The same for the general epilogue (any K: nwin 256 / 512, or nwin 128 with an odd or wide band), STACK only.  The z-score
+// tickets sweep a chunk as float4s: every signal's feature block has to start on a 16-byte boundary.
+template <int NT, int RQ, int WPB, int S1C>
+int launch_fused_general(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + kFpw128 / 16 - 1) / (kFpw128 / 16) < hssfsst::kFusedMinChunks) return 0;
+    if (((static_cast<long long>(cp.ncols) * 2 * pl->K) & 3) != 0 || (reinterpret_cast<uintptr_t>(cp.out) & 15) != 0) return 0;
+    const size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
+                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ, NT)) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, false, WPB, S1C, true>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->fused_slots == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->fused_slots = (per_cu >= 1 && cus >= 1) ? cus : -1;       // one block per CU
+    }
+    if (pl->fused_slots < 1) return 0;
+    const int64_t grid = pl->fused_slots;
+    const int64_t rounds = (batch + grid - 1) / grid;
+    if (batch < grid || rounds * grid * 100 > batch * 112) return 0;  // (as launch_fused128: a nearly full last round)
+    if (int rcs = ensure_status(pl)) return rcs;
+    cp.status = pl->d_status;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
+    HIP_TRY(hipGetLastError());
+    return 1;
+}
+
 // The status word of the in-kernel waits lives in pinned, device-mapped host memory: a kernel that gave up writes it
 // with a system-scope store, and the host looks at it without synchronising (at the start of the next exec, in
 // hssfsst_plan_check after a synchronisation, at plan destruction).
@@ -401,19 +431,21 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
 #ifdef HSS_TEAM_PROBE
     static unsigned long long* d_probe = nullptr;
     static int probe_runs = 0;
-    if (!d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_probe), 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_probe, 0, 16 * sizeof(unsigned long long), st));
+    if (!d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_probe), 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_probe, 0, 32 * sizeof(unsigned long long), st));
     tp.probe = d_probe;
 #endif
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * kTeamWaves), lds, st, tp);
     HIP_TRY(hipGetLastError());
 #ifdef HSS_TEAM_PROBE
     if (++probe_runs % 40 == 0) {
-        unsigned long long h[16];
+        unsigned long long h[32];
         HIP_TRY(hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost));
         const double w = static_cast<double>(h[8] ? h[8] : 1);
         fprintf(stderr, "[team probe] waves %llu, cycles per wave: window %.0f transform %.0f publish+draw %.0f poll %.0f stats %.0f zscore+stores %.0f rest %.0f | lifetime %.0f | resolves %llu prefetched %llu ready %llu\n",
                 h[8], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[7] / w, h[6] / w, h[9], h[10], h[11]);
+        fprintf(stderr, "[team probe] transform per wave: fold %.0f fft %.0f source %.0f flags+rare %.0f stats+blocksum %.0f image %.0f\n",
+                h[16] / w, h[17] / w, h[18] / w, h[19] / w, h[20] / w, h[21] / w);
     }
 #endif
     return 1;
@@ -550,6 +582,29 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (rc < 0) return rc;
         if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
     }
+    if (try_fused && !fast && rq == 8 && nt == 16 && pl->mode == HSSFSST_MODE_STACK && pl->zpath_pref != HSSFSST_ZPATH_TEAM &&
+        fixed + 16 * per_wave <= room) {
+        // nwin 128, a band the wide-store epilogue does not take (odd K or K > 24)
+        const int rc = launch_fused_general<16, 8, 16, -1>(pl, cp, batch, (ncols + 15) / 16, st);
+        if (rc < 0) return rc;
+        if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
+    }
+#ifndef HSS_DEV_ONLY128
+    if (try_fused && !fast && rq == 16 && pl->mode == HSSFSST_MODE_STACK && pl->zpath_pref != HSSFSST_ZPATH_TEAM) {
+        // nwin 256 / 512 (general epilogue): one CU per signal, the z-score as tickets of the same launch; waves per block
+        // as on the two-launch path (what fits the LDS: 8 for the canonical band at 256 points, 3 at 512)
+        const int ngroups = (ncols + 15) / 16;
+        int rc = 0;
+        if (nt == 16 && fixed + 8 * per_wave <= room)
+            rc = canon ? launch_fused_general<16, 16, 8, 3>(pl, cp, batch, ngroups, st) : launch_fused_general<16, 16, 8, -1>(pl, cp, batch, ngroups, st);
+        else if (nt == 32 && fixed + 8 * per_wave <= room) rc = launch_fused_general<32, 16, 8, -1>(pl, cp, batch, ngroups, st);
+        else if (nt == 32 && fixed + 6 * per_wave <= room) rc = 0;                       // (6 waves: two launches)
+        else if (nt == 32 && fixed + 4 * per_wave <= room) rc = launch_fused_general<32, 16, 4, -1>(pl, cp, batch, ngroups, st);
+        else if (nt == 32 && fixed + 3 * per_wave <= room) rc = launch_fused_general<32, 16, 3, -1>(pl, cp, batch, ngroups, st);
+        if (rc < 0) return rc;
+        if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
+    }
+#endif
     if (nt == 16 && rq == 8) {
         if (canon16) return launch_canon(pl, cp, nchunks, st);
 #ifdef HSS_WPB_CANON
@@ -692,6 +747,26 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             const double ang = 2.0 * M_PI * static_cast<double>(i) / static_cast<double>(nwin);
             wt[2 * nwin + 2 * i] = std::cos(ang); wt[2 * nwin + 2 * i + 1] = std::sin(ang);
         }
+        if (nwin == 128) {
+            // nwin = 128 kernels, heavily undecided groups (resolve_group_f64, fsst_mfma128.hpp): the A operand of the fold
+            // -- the constants C_r[n, q] of the float32 table below, [tap][k-step][lane] -- in float64 for
+            // v_mfma_f64_16x16x4_f64, behind the twiddles (16 kB, L1-resident while it is used).  The float64 instruction
+            // hands lane group g the rows g, g + 4, g + 8, g + 12 of D (measured: tools/mfma_f64_layout.hip) where the
+            // float32 one hands it rows 4 g .. 4 g + 3: row i of A is class pair i & 3, component i >> 2.
+            wt.resize(static_cast<size_t>(4) * nwin + hssfsst::kFold64Doubles);
+            for (int n = 0; n < 16; ++n)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = l & 15, q = (l >> 4) + 4 * ks;
+                        const int gg = i & 3, sub = i >> 2;
+                        const int r = (sub < 2) ? gg : (gg ? 8 - gg : 4);
+                        const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / 8 + static_cast<double>(r) * n / nwin);
+                        const double c = std::cos(ang), sn = std::sin(ang);
+                        const double sg = (r & 1) ? -0.5 : 0.5;
+                        const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
+                        wt[static_cast<size_t>(4) * nwin + ((n * 2) + ks) * 64 + l] = (sub & 1) ? sg * (wv * sn + dv * c) : sg * (wv * c - dv * sn);
+                    }
+        }
         e = hipMalloc(reinterpret_cast<void**>(&p->d_wtab), wt.size() * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(p->d_wtab, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -797,7 +872,14 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             if (cmax > 0.0 && std::isfinite(cmax)) (void)std::frexp(cmax, &ex);          // cmax = f 2^ex, f in [0.5, 1)
             const int sc = 14 - ex;                                                       // cmax 2^sc in [2^13, 2^14)
             const double cs = std::ldexp(1.0, sc);
-            std::vector<unsigned short> ht(static_cast<size_t>(16) * 64 * 8);
+            // (+ the float64 twiddles of the rounding-tie path, 2 kB: the kernels copy the whole table into LDS)
+            std::vector<unsigned short> ht(static_cast<size_t>(hssfsst::kCanonAtabFloats) * 2);
+            static_assert(hssfsst::kCanonAtabFloats == 16 * 64 * 4 + 4 * 128, "f16 operand table + 128 {cos, sin} doubles");
+            for (int i = 0; i < 128; ++i) {
+                const double ang = 2.0 * M_PI * static_cast<double>(i) / 128.0;
+                const double cs2[2] = {std::cos(ang), std::sin(ang)};
+                std::memcpy(ht.data() + static_cast<size_t>(16) * 64 * 8 + static_cast<size_t>(i) * 8, cs2, sizeof(cs2));
+            }
             for (int n = 0; n < 16; ++n)
                 for (int l = 0; l < 64; ++l)
                     for (int h = 0; h < 8; ++h) {

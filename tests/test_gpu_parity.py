@@ -634,6 +634,33 @@ def test_zpath_preference_is_bit_identical(batch):
         tf.set_zpath("fastest")
 
 
+@pytest.mark.parametrize("nwin,n,batch", [(256, 2000, 256), (256, 2000, 300), (256, 1504, 512), (256, 1999, 256), (512, 2000, 256),
+                                          (128, 2000, 256)])
+def test_general_band_single_launch_zscore_is_bit_identical(oracle_mod, nwin, n, batch):
+    """The one-CU-per-signal z-score of the general epilogue (any K: the canonical band at 256 / 512 points has K = 45 / 90,
+    and at 128 points the odd band [25, 210] Hz): tickets of the core launch that sweep a chunk as float4s with the
+    arithmetic of fsst_normalize_kernel -- the same bits as two launches, whichever path the shape takes (300 signals do
+    not fill the last round of 256 CUs; 1999 x 90 floats per signal are not a multiple of 16 bytes: both stay two
+    launches), and parity with the oracle on a few signals of the batch."""
+    w = synth.kaiser_window(nwin, 0.5)
+    band = (25, 210) if nwin == 128 else BAND
+    X = torch.from_numpy(synth.pcg_windows(batch, n, seed=nwin + n)).cuda()
+    tf = FSST(1000, w, truncate_freq=band, stack=True)
+    tf.set_zpath("two_launch")
+    ref = tf.batch(X).clone()
+    assert tf.check() == 0
+    tf.set_zpath("auto")
+    got = tf.batch(X)
+    path = tf.check()
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        want = 1 if (batch in (256, 512) and (n * ref.shape[-1]) % 4 == 0) else 0
+        assert path == want, (path, want)
+    assert torch.equal(got, ref)
+    o, hd = oracle_mod.features(X[:3].cpu().numpy(), 1000, w, band, "stack", return_halfdist=True)
+    for b in range(3):
+        parity.check(got[b].cpu().numpy(), o[b], hd[b], 0, what=f"nwin {nwin} signal {b}")
+
+
 _FALLBACK_CHILD = r"""
 import sys, torch
 from heart_sounds_segmentation_amd import FSST, synth
