@@ -500,7 +500,9 @@ int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nch
 }
 
 // One CU per signal with the z-score in the same launch (see launch_fused128): 1 = launched, 0 = take another path
-int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st)
+// gated = the fallback queued behind a team launch (pl->gate set): any batch size -- the block count is what a launch that
+// almost always finds its gate closed should cost, not what would be fast.
+int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st, bool gated = false)
 {
     constexpr int WPB = 16, GPC = hssfsst::kCanonTileFrames / 16;
     if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + GPC - 1) / GPC < hssfsst::kFusedMinChunks) return 0;
@@ -516,9 +518,10 @@ int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batc
         pl->fused_slots = (per_cu >= 1 && cus >= 1) ? cus : -1;
     }
     if (pl->fused_slots < 1) return 0;
-    const int64_t grid = pl->fused_slots;
+    int64_t grid = pl->fused_slots;
     const int64_t rounds = (batch + grid - 1) / grid;
-    if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
+    if (gated) grid = batch < 64 ? batch : 64;
+    else if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
@@ -573,6 +576,12 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
                 // kernel of it gated on the abort word -- a few microseconds of empty launches when nothing went wrong
                 pl->last_zpath = 2;
                 pl->gate = pl->d_arrive + 1; pl->gate_val = pl->team_launch;
+                // ONE gated launch where the one-CU-per-signal kernel applies (signals of 16 .. 32 chunks; its batch
+                // conditions are about speed only): 4 us behind the team kernel instead of 11 for transform + statistics +
+                // z-score launches -- a third of a 50-window exec
+                const int rc1 = launch_canon_fused(pl, cp, batch, ngroups, st, true);
+                if (rc1 < 0) { pl->gate = nullptr; return rc1; }
+                if (rc1 == 1) { pl->gate = nullptr; *did_fuse = true; return 0; }
                 const int rc2 = launch_canon(pl, cp, nchunks, st);
                 if (rc2 != 0) { pl->gate = nullptr; return rc2; }
                 *did_fuse = false;                       // (exec_impl adds the gated statistics + z-score launches)

@@ -670,7 +670,11 @@ tf = FSST(1000, w, truncate_freq=(25, 200), stack=True)
 got = tf.batch(X)
 path = tf.check()
 print("PATH", path, "FALLBACKS", tf.fallbacks())
-torch.save(got.cpu(), sys.argv[1])
+# 500-sample signals: 8 chunks each -- the gated fallback is then three launches (transform, statistics, z-score), not the
+# one-CU-per-signal kernel that backs the 2000-sample exec up
+got2 = tf.batch(torch.from_numpy(synth.pcg_windows(40, 500, seed=6)).cuda())
+print("PATH2", tf.check(), "FALLBACKS2", tf.fallbacks())
+torch.save((got.cpu(), got2.cpu()), sys.argv[1])
 """
 
 
@@ -689,7 +693,9 @@ def test_team_kernel_fallback_and_other_processes(tmp_path):
         outs[name] = (torch.load(f), r.stdout)
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
         assert "PATH 2 FALLBACKS 0" in outs["plain"][1] and "PATH 2 FALLBACKS 1" in outs["forced"][1] and "PATH 0" in outs["two"][1], [o[1] for o in outs.values()]
-    assert torch.equal(outs["plain"][0], outs["forced"][0]) and torch.equal(outs["plain"][0], outs["two"][0])
+        assert "PATH2 2 FALLBACKS2 0" in outs["plain"][1] and "PATH2 2 FALLBACKS2 2" in outs["forced"][1], [o[1] for o in outs.values()]
+    for i in range(2):
+        assert torch.equal(outs["plain"][0][i], outs["forced"][0][i]) and torch.equal(outs["plain"][0][i], outs["two"][0][i])
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "team_stress.py"), "3", "200"], cwd=root, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "exit codes [0, 0, 0]" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
 
