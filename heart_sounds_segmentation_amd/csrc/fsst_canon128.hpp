@@ -423,6 +423,10 @@ __device__ __forceinline__ void canon_fetch(const float* xsig, int n, int t0, in
 // fsst_canon_kernel: work distribution, tickets and the FUSED z-score exactly as fsst_core128_kernel (see there:
 // "Work distribution", "Fused z-score"); the body of a transform chunk is canon_group + canon_stats + canon_image.
 // ------------------------------------------------------------------------------------------------
+#ifdef HSS_FUSE_PROBE      // development (tools/fuse_probe2.py): shader-clock totals per ticket kind over all waves of the FUSED kernel
+__device__ unsigned long long g_fuse_probe[8];      // [0] A tickets [1] cycles in A [2] B tickets [3] B: wait for statistics
+                                                    // [4] B: loads issued -> data there [5] B: arithmetic + stores issued [6] resolver
+#endif
 template <int KLO, int KC, bool FUSED>
 __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonParams p)
 {
@@ -489,7 +493,14 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
     int chunk = draw();
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
+#ifdef HSS_FUSE_PROBE
+    unsigned long long fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FPROBE_NOW() __builtin_readcyclecounter()
+#endif
     while (chunk < nwork) {
+#ifdef HSS_FUSE_PROBE
+    const unsigned long long fp_t0 = FPROBE_NOW();
+#endif
     long long b;
     int grp0, ngrp;
     long long ksig = 0;
@@ -546,6 +557,9 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
             __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef HSS_FUSE_PROBE
+        const unsigned long long fp_t1 = FPROBE_NOW();
+#endif
         const float4 st = fin_stats[sl];
         const unsigned cls = cls_lds[lane_o];
         const float4* base0 = reinterpret_cast<const float4*>(p.out + (b * static_cast<long long>(ncols) + grp0 * 16) * CC);
@@ -570,6 +584,10 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
                 mu[i][0] = f2{m0, m0}; rs[i][0] = f2{r0, r0};
                 mu[i][1] = f2{m1, m1}; rs[i][1] = f2{r1, r1};
             }
+#ifdef HSS_FUSE_PROBE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long fp_t2 = FPROBE_NOW();
+#endif
 #pragma unroll
             for (int q = 0; q < GPCF; ++q) {
                 const int lim = glim(q);
@@ -582,6 +600,10 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
                     }
                 }
             }
+#ifdef HSS_FUSE_PROBE
+            const unsigned long long fp_t3 = FPROBE_NOW();
+            fp[2] += 1; fp[3] += fp_t1 - fp_t0; fp[4] += fp_t2 - fp_t1; fp[5] += fp_t3 - fp_t2;
+#endif
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
@@ -634,6 +656,10 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
         }
         gcur = gstop;
     }
+#ifdef HSS_FUSE_PROBE
+    const unsigned long long fp_ta = FPROBE_NOW();
+    fp[0] += 1; fp[1] += fp_ta - fp_t0;
+#endif
     if constexpr (FUSED) {
         const int sl = static_cast<int>(ksig) & 1;
         unsigned before = 0;
@@ -649,11 +675,17 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
                 __hip_atomic_store(ready + (static_cast<int>(ksig) & 3), static_cast<unsigned>(ksig) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_sync();
+#ifdef HSS_FUSE_PROBE
+            fp[6] += FPROBE_NOW() - fp_ta;
+#endif
         }
     }
     }
     chunk = draw();
     }
+#ifdef HSS_FUSE_PROBE
+    if (FUSED && lane == 0) for (int k = 0; k < 7; ++k) atomicAdd(g_fuse_probe + k, fp[k]);
+#endif
 }
 
 }  // namespace hssfsst

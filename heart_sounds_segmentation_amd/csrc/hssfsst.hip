@@ -649,6 +649,17 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
 }  // namespace
 
 extern "C" {
+#ifdef HSS_FUSE_PROBE
+// development: read and clear the ticket probes of fsst_canon_kernel<.., true> (fsst_canon128.hpp)
+int hssfsst_dev_fuse_probe(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hssfsst::g_fuse_probe), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_fuse_probe), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 int hssfsst_version(void) { return HSSFSST_VERSION; }
 const char* hssfsst_last_error(void) { return g_err; }
