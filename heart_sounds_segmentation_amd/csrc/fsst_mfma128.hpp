@@ -407,19 +407,21 @@ __device__ __forceinline__ d2v tie_twiddle(const double* twtab, int idx)
     if constexpr (TWLDS) return ((const lds_d2v*)reinterpret_cast<const d2v*>(twtab))[idx];
     else return reinterpret_cast<const d2v*>(twtab)[idx];
 }
-// Heavily undecided groups at nwin = 128 (an on-bin tone under a near-rectangular window, a band that holds only leakage:
-// ~1000 of the group's 1024 (source, frame) cells).  One float64 DFT per cell is 128 taps x 4 FMAs; done for all cells it is the
-// fold + 16-point DFT factorisation of the float32 kernel in float64 instead: per tap ONE pair of v_mfma_f64_16x16x4_f64
+// Heavily undecided groups (an on-bin tone under a near-rectangular window, a band that holds only leakage: ~all of the group's
+// 16 nwin / 2 (source, frame) cells).  One float64 DFT per cell is nwin taps x 4 FMAs; done for all cells it is the fold +
+// NT-point DFT factorisation of the float32 kernel in float64 instead: per tap ONE chain of RQ / 4 v_mfma_f64_16x16x4_f64
 // gives lane (g, j) the folded {Za, Zb}[tap] of its two classes for frame j (A operand: the float64 table a64 behind the
 // twiddles of `wtab`, made by the host with the row order of the float64 instruction; B operand: the float32 samples, exact
-// in float64), and the lane accumulates the 16-point DFT outputs of ONE stripe at a time (8 passes: registers) -- X = Z[8 s + r]
-// and its conjugate partner, as process_stripe.  16 complex multiply-adds per cell instead of 128 real-complex ones.
-// Measured on an on-bin tone (every group): 22.8 -> 2.9 ms per 1024 windows, 1.0 of it the displaced cells themselves.  The
-// fold is redone in every pass (64 cycles per float64 matrix instruction on this chip: ~40 % of the path); holding its 16 x 4
-// doubles per lane would take 128 registers, two stripes per pass made the 128-register kernels spill, and making the A
-// operand on the spot from the window pair and twiddles in LDS instead of loading it was slower (4.3 ms).
-// sample(i): sample i of the group's first frame.
-constexpr int kFold64Doubles = 16 * 2 * 64;
+// in float64), and the lane accumulates the NT-point DFT outputs of SPP stripes at a time (registers) -- X = Z[RQ s + r] and
+// its conjugate partner, as process_stripe.  NT complex multiply-adds per cell instead of nwin real-complex ones.
+// Measured at 128 points on an on-bin tone (every group): 22.8 -> 2.9 ms per 1024 windows, 1.0 of it the displaced cells
+// themselves.  The fold is redone in every pass (64 cycles per float64 matrix instruction on this chip: ~40 % of the path at 128
+// points); holding its NT x 4 doubles per lane would take 128 / 256 registers, two stripes per pass made the 128-register
+// kernels spill (SPP = 1 there; the 256-register kernels of 256 / 512 points take 4 / 2), and making the A operand on the spot
+// from the window pair and twiddles in LDS instead of loading it was slower (4.3 ms).
+// XREG: the B operand's samples are fetched once into registers (the canonical-band kernels: sample() is a load from HBM / L2);
+// otherwise sample() is called per tap (a read of the float32 tile in LDS).  sample(i): sample i of the group's first frame.
+__host__ __device__ constexpr int fold64_doubles(int rq, int nt) { return (rq / 8) * nt * (rq / 4) * 64; }
 __device__ __forceinline__ d2v uniform_d2v(d2v v)
 {
     auto u = [](double x) -> double {
@@ -431,8 +433,86 @@ __device__ __forceinline__ d2v uniform_d2v(d2v v)
     return d2v{u(v.x), u(v.y)};
 }
 using d4v = double __attribute__((ext_vector_type(4)));
-template <bool REFRESH, bool TWLDS, class Sample>
+template <int NT, int RQ, int SPP, bool XREG, bool REFRESH, bool TWLDS, class Sample>
 __device__ __forceinline__ void resolve_group_f64(const unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
+                                                  f2* own_base, int OLD, int cov0, int cov1, const double* a64, const double* twtab,
+                                                  double plane_scale, int lane)
+{
+    constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
+    static_assert((NT / 2) % SPP == 0, "whole passes");
+    const int g = lane >> 4, j = lane & 15;
+    float xs[XREG ? KST : 1][XREG ? NT : 1];             // B operand rows kk = g + 4 ks of every tap: x[j + n + NT kk]
+    if constexpr (XREG) {
+#pragma unroll
+        for (int h = 0; h < KST; ++h)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) xs[h][n] = static_cast<float>(sample(j + n + NT * (g + 4 * h)));
+    }
+    // this lane's flagged frames: bit (k' & 1) * 16 + j of word k' >> 1
+    auto flagged = [&](int kp) -> bool { return REFRESH || ((tb[kp >> 1] >> (((kp & 1) << 4) + j)) & 1u) != 0u; };
+    auto cmac = [](double& ar, double& ai, double zr, double zi, d2v cs) {      // a += z (cos - i sin)
+        ar = fma(zr, cs.x, ar); ar = fma(zi, cs.y, ar);
+        ai = fma(zi, cs.x, ai); ai = fma(-zr, cs.y, ai);
+    };
+#pragma unroll 1
+    for (int pz = 0; pz < NPASS; ++pz) {
+        const int pair = 4 * pz + g;
+        const bool isg0 = pair == 0;                         // the self-conjugate classes {0, RQ / 2}
+        const int rA = pair, rB = isg0 ? RQ / 2 : RQ - pair;
+        const double* ap = a64 + pz * (NT * KST * 64);       // (uniform base + lane index: no per-lane 64-bit pointer to hold)
+#pragma unroll 1
+        for (int s0 = 0; s0 < NT / 2; s0 += SPP) {
+            double xa[SPP][2], xb[SPP][2], pza[SPP][2], pzb[SPP][2];
+#pragma unroll
+            for (int u = 0; u < SPP; ++u) { xa[u][0] = xa[u][1] = xb[u][0] = xb[u][1] = pza[u][0] = pza[u][1] = pzb[u][0] = pzb[u][1] = 0.0; }
+#pragma unroll 4
+            for (int n = 0; n < NT; ++n) {
+                d4v z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    const double a = ap[(n * KST + ks) * 64 + lane];
+                    double x;
+                    if constexpr (XREG) x = static_cast<double>(xs[ks][n]);
+                    else x = sample(j + n + NT * (g + 4 * ks));
+                    z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x, z, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < SPP; ++u) {
+                    const int s = s0 + u;
+                    const int ia = isg0 ? ((NT - s) & (NT - 1)) : NT - 1 - s;    // partner index in array a (process_stripe)
+                    // (t1, t2 are the same in every lane: scalar registers -- eight vector registers the 128-register kernels lack)
+                    const d2v t1 = uniform_d2v(tie_twiddle<TWLDS>(twtab, (RQ * s * n) & (NWIN - 1)));
+                    const d2v t2 = uniform_d2v(tie_twiddle<TWLDS>(twtab, (RQ * (NT - 1 - s) * n) & (NWIN - 1)));
+                    const d2v t3 = tie_twiddle<TWLDS>(twtab, (RQ * ia * n) & (NWIN - 1));
+                    cmac(xa[u][0], xa[u][1], z.x, z.y, t1);
+                    cmac(xb[u][0], xb[u][1], z.z, z.w, t1);
+                    cmac(pzb[u][0], pzb[u][1], z.z, z.w, t2);
+                    cmac(pza[u][0], pza[u][1], z.x, z.y, t3);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SPP; ++u) {
+                const int s = s0 + u;
+                const double par = isg0 ? pza[u][0] : pzb[u][0], pai = isg0 ? pza[u][1] : pzb[u][1];      // partner of source a
+                const double pbr = isg0 ? pzb[u][0] : pza[u][0], pbi = isg0 ? pzb[u][1] : pza[u][1];      // partner of source b
+                const int ka = RQ * s + rA, kb = RQ * s + rB;
+                // plane values (-1)^k' V = X + conj(P), (-1)^k' Vd' = (X - conj(P)) / i; resolve_one takes V, Vd' themselves
+                const double sa = (ka & 1) ? -1.0 : 1.0, sb = (kb & 1) ? -1.0 : 1.0;
+                if (flagged(ka))
+                    resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, ka, j,
+                                               sa * (xa[u][0] + par), sa * (xa[u][1] - pai), sa * (xa[u][1] + pai), sa * (par - xa[u][0]), plane_scale);
+                if (flagged(kb))
+                    resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kb, j,
+                                               sb * (xb[u][0] + pbr), sb * (xb[u][1] - pbi), sb * (xb[u][1] + pbi), sb * (pbr - xb[u][0]), plane_scale);
+            }
+        }
+    }
+}
+
+// nwin = 128 (16 taps, radix 8, one stripe per pass, samples in registers): the same, written out for the 128-register kernels
+// -- the general form above needs a few registers more than they have.
+template <bool REFRESH, bool TWLDS, class Sample>
+__device__ __forceinline__ void resolve_group_f64_128(const unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
                                                   f2* own_base, int OLD, int cov0, int cov1, const double* a64, const double* twtab,
                                                   double plane_scale, int lane)
 {
@@ -492,6 +572,41 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
     constexpr int NSETS = NWIN / 128;                   // sets of 32 words = 64 sources
     int lane = lane_in;                                 // opaque HERE, inside the rare branch: nothing this function derives
     asm volatile("" : "+v"(lane));                      // from the lane id is computed per chunk, held across the transform and spilled
+    if constexpr (NWIN == 128 || NWIN == 256 || NWIN == 512) {
+        // from kTieGroup64 undecided cells per 64 sources on (and for every exact group): the whole group in float64 at once
+        int total = 0;
+        if constexpr (!REFRESH) {
+            int cnt = 0;
+#pragma unroll
+            for (int set = 0; set < NSETS; ++set) cnt += (lane < 32) ? __popc(tb[32 * set + lane]) : 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((cnt >> b) & 1)) << b;
+        }
+        if (REFRESH || total >= kTieGroup64 * NSETS) {
+            constexpr int NT = NWIN == 512 ? 32 : 16, RQ = NWIN / NT;
+            constexpr int SPP = NWIN == 128 ? 1 : 4;
+            if constexpr (NWIN == 128)
+                resolve_group_f64_128<REFRESH, TWLDS>(tb, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, wtab + 4 * NWIN, twtab,
+                                                      plane_scale, lane);
+            else
+                resolve_group_f64<NT, RQ, SPP, false, REFRESH, TWLDS>(tb, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1,
+                                                                     wtab + 4 * NWIN, twtab, plane_scale, lane);
+            for (int i = lane; i < 32 * NSETS; i += 64) tb[i] = 0u;
+            if constexpr (REFRESH) {
+                if (cov1 > NWIN / 2 && lane < 16) {          // the Nyquist row (see below)
+                    double vr = 0.0;
+#pragma unroll 1
+                    for (int n = 0; n < NWIN; ++n) {
+                        const double xw = sample(lane + n) * wtab[2 * n];
+                        vr = (n & 1) ? vr - xw : vr + xw;
+                    }
+                    own_base[lane * OLD + (NWIN / 2 - cov0)] = f2{static_cast<float>(vr * plane_scale), 0.0f};
+                }
+            }
+            if (lane == 0) flag[1] = 0;
+            return;
+        }
+    }
 #pragma unroll 1
     for (int set = 0; set < NSETS; ++set) {
         unsigned* tbs = tb + 32 * set;
@@ -503,14 +618,6 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
         for (int b = 0; b < 6; ++b) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((cnt >> b) & 1)) << b;
         if constexpr (REFRESH) total = 1024;
         if (total == 0) continue;
-        if constexpr (NWIN == 128) {
-            if (total >= kTieGroup64) {
-                resolve_group_f64<REFRESH, TWLDS>(tbs, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, wtab + 4 * NWIN, twtab,
-                                                  plane_scale, lane);
-                if (lane < 32) tbs[lane] = 0u;
-                continue;
-            }
-        }
         if (total <= kTieCoop) {
             // few cells: one by one, all lanes on one cell (NWIN / 64 taps per lane, float64 butterfly sum)
             for (int it = 0; it < total; ++it) {

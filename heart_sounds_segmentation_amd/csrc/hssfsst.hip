@@ -767,25 +767,28 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             const double ang = 2.0 * M_PI * static_cast<double>(i) / static_cast<double>(nwin);
             wt[2 * nwin + 2 * i] = std::cos(ang); wt[2 * nwin + 2 * i + 1] = std::sin(ang);
         }
-        if (nwin == 128) {
-            // nwin = 128 kernels, heavily undecided groups (resolve_group_f64, fsst_mfma128.hpp): the A operand of the fold
-            // -- the constants C_r[n, q] of the float32 table below, [tap][k-step][lane] -- in float64 for
-            // v_mfma_f64_16x16x4_f64, behind the twiddles (16 kB, L1-resident while it is used).  The float64 instruction
-            // hands lane group g the rows g, g + 4, g + 8, g + 12 of D (measured: tools/mfma_f64_layout.hip) where the
-            // float32 one hands it rows 4 g .. 4 g + 3: row i of A is class pair i & 3, component i >> 2.
-            wt.resize(static_cast<size_t>(4) * nwin + hssfsst::kFold64Doubles);
-            for (int n = 0; n < 16; ++n)
-                for (int ks = 0; ks < 2; ++ks)
-                    for (int l = 0; l < 64; ++l) {
-                        const int i = l & 15, q = (l >> 4) + 4 * ks;
-                        const int gg = i & 3, sub = i >> 2;
-                        const int r = (sub < 2) ? gg : (gg ? 8 - gg : 4);
-                        const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / 8 + static_cast<double>(r) * n / nwin);
-                        const double c = std::cos(ang), sn = std::sin(ang);
-                        const double sg = (r & 1) ? -0.5 : 0.5;
-                        const double wv = window[n + 16 * q], dv = dwb[n + 16 * q];
-                        wt[static_cast<size_t>(4) * nwin + ((n * 2) + ks) * 64 + l] = (sub & 1) ? sg * (wv * sn + dv * c) : sg * (wv * c - dv * sn);
-                    }
+        if (nwin == 128 || nwin == 256 || nwin == 512) {
+            // MFMA kernels, heavily undecided groups (resolve_group_f64, fsst_mfma128.hpp): the A operand of the fold -- the
+            // constants C_r[n, q] of the float32 table below, [pass][tap][k-step][lane] -- in float64 for
+            // v_mfma_f64_16x16x4_f64, behind the twiddles (16 / 64 / 128 kB).  The float64 instruction hands lane group g the
+            // rows g, g + 4, g + 8, g + 12 of D (measured: tools/mfma_f64_layout.hip) where the float32 one hands it rows
+            // 4 g .. 4 g + 3: row i of A is class pair 4 pz + (i & 3), component i >> 2.
+            const int nt = (nwin == 512) ? 32 : 16, rq = nwin / nt, npass = rq / 8, kst = rq / 4;
+            wt.resize(static_cast<size_t>(4) * nwin + static_cast<size_t>(hssfsst::fold64_doubles(rq, nt)));
+            for (int pz = 0; pz < npass; ++pz)
+                for (int n = 0; n < nt; ++n)
+                    for (int ks = 0; ks < kst; ++ks)
+                        for (int l = 0; l < 64; ++l) {
+                            const int i = l & 15, q = (l >> 4) + 4 * ks;
+                            const int gg = i & 3, sub = i >> 2, m = 4 * pz + gg;
+                            const int r = (sub < 2) ? m : (m ? rq - m : rq / 2);
+                            const double ang = -2.0 * M_PI * (static_cast<double>(r) * q / rq + static_cast<double>(r) * n / nwin);
+                            const double c = std::cos(ang), sn = std::sin(ang);
+                            const double sg = (r & 1) ? -0.5 : 0.5;
+                            const double wv = window[n + nt * q], dv = dwb[n + nt * q];
+                            wt[static_cast<size_t>(4) * nwin + (((pz * nt + n) * kst) + ks) * 64 + l] =
+                                (sub & 1) ? sg * (wv * sn + dv * c) : sg * (wv * c - dv * sn);
+                        }
         }
         e = hipMalloc(reinterpret_cast<void**>(&p->d_wtab), wt.size() * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(p->d_wtab, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice);
