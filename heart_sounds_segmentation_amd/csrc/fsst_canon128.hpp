@@ -168,7 +168,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #else
 #define CPROBE(k) do { } while (0)
 #endif
-    const int g = lane_o >> 4, j = lane_o & 15;
+    const int g = (lane_o >> 4) & 3, j = lane_o & 15;    // (& 3: see canon_stats)
     const double* tw_lds = reinterpret_cast<const double*>(atab + kCanonOpFloats);   // the twiddles' copy in LDS (twtab: in HBM)
     (void)twtab;
     // lane (kk = g, f = j) is row-block kk of the B operand for frame f: records f + tap + 16 kk and + 64 (fold terms kk, kk + 4:
@@ -321,7 +321,9 @@ template <int KLO, int KC>
 __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, float inv, int lane_o, f2& piv_out)
 {
     using C = CanonCfg<KLO, KC>;
-    const int g = lane_o >> 4, j = lane_o & 15;
+    // (& 3: the compiler cannot see through the opaque lane copy that g < 4 -- without it every "g + 4 u < KC" below is a
+    //  compare and two selects, with it only the one row group that is partial across lanes)
+    const int g = (lane_o >> 4) & 3, j = lane_o & 15;
     const f2* src = own_base + j * C::LD + C::KOFF + g;
     const f2 piv = own_base[C::KOFF];                    // frame 0, row KLO: one address, broadcast
     constexpr int NU = (KC + 3) / 4, UF = KC / 4;        // rows g + 4 u: u < UF valid in every lane group, u == UF for g < KC - 4 UF
@@ -329,7 +331,7 @@ __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, flo
 #pragma unroll
     for (int u = 0; u < NU; ++u) v[u] = src[4 * u];
     f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};
-    if (nvalid == 16) {
+    if (__builtin_expect(nvalid == 16, 1)) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             f2 d = v[u] - piv;
@@ -337,6 +339,7 @@ __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, flo
             st_s += d; st_q = pk_fma(d, d, st_q);
         }
     } else {
+        asm volatile("");                                // (keeps the two arms apart: merged, the full group pays for the ragged one's selects)
         const bool jv = j < nvalid;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -607,6 +610,9 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
+    // per-signal bases once per ticket (uniform): the group loop then adds 32-bit offsets (was: a 64-bit multiply per group)
+    float* out_sig = p.out + b * static_cast<long long>(ncols) * (2 * K);
+    float* part_sig = FUSED ? nullptr : p.partials + b * static_cast<long long>(ngroups) * kPartFloats;
     const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     for (int gcur = grp0; gcur < grp0 + ngrp;) {
         // the ALIGNED tile of the signal that holds group gcur: aligned in absolute columns, so that a column-range exec
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
                 f2 piv;
                 const float w = canon_stats<KLO, KC>(own_base, nvalid, tile.inv, lane_o, piv);
                 if constexpr (FUSED) store_partial(part_lds + ((static_cast<int>(ksig) & 1) * kFusedMaxGroups + gidx) * kPartFloats, w, piv.x, piv.y);
-                else store_partial(p.partials + (b * ngroups + gidx) * kPartFloats, w, piv.x, piv.y);
+                else store_partial(part_sig + gidx * kPartFloats, w, piv.x, piv.y);
             }
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 1
             if (tg == 123456789) {
@@ -641,15 +647,26 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
 #endif
             f4 o[3];
             canon_image<KLO, KC>(own_base, ppk_lds, tile.inv, lane_o, o);
-            float4* dst4 = reinterpret_cast<float4*>(p.out + (b * static_cast<long long>(ncols) + (tg - p.col0)) * (2 * K)) + lane_o;
+            float4* dst4 = reinterpret_cast<float4*>(out_sig + (tg - p.col0) * (2 * K)) + lane_o;
             const int lim = nvalid * (K >> 1);
             asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+            auto put = [&](int i) {
+                if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
+                else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+            };
+            if (__builtin_expect(nvalid == 16, 1)) {
+                // a full group is 8 K float4s: every lane has the first (8 K / 64) of its three, one predicate for the rest
+                // (three compare + exec-mask + branch sequences otherwise)
+                static_for<3>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr (64 * (i + 1) <= 8 * K) put(i);
+                    else if constexpr (64 * i < 8 * K) { if (lane_o + 64 * i < 8 * K) put(i); }
+                });
+            } else {
+                asm volatile("");
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (lane_o + 64 * i < lim) {
-                    if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
-                    else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
-                }
+                for (int i = 0; i < 3; ++i)
+                    if (lane_o + 64 * i < lim) put(i);
             }
             }
             wave_sync();

@@ -174,6 +174,12 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
     const double total = static_cast<double>(K) * static_cast<double>(ncols);
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * kTeamMailSlots * NC * 8;
     const unsigned t_start = static_cast<unsigned>(wall_clock64());
+    // Parameters used once per chunk are re-read from the kernel-argument segment where they are used (scalar loads) instead of
+    // living in scalar registers across the whole work loop: the loop holds ~130 wave-uniform values, the register file 100
+    // (the compiler spilled 104 of them to lanes of a vector register: ~170 v_readlane / v_writelane per chunk).
+    using kparams = const __attribute__((address_space(4))) Team128Params;
+    kparams* const kp_ = (kparams*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto P = [&]() -> kparams* { kparams* q = kp_; asm volatile("" : "+s"(q)); return q; };
 
     const float* myA = atab + lane * KST;
     f2 tiny = {1.0e-37f, 0.0f};
@@ -181,23 +187,23 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
 
     // Giving up.  Blocks of a team wait for each other, and nothing guarantees that they are resident together when other
     // processes use the GPU (workgroups are dealt to the XCDs in order: a launch can stall on a full XCD while the blocks it
-    // did place hold CUs and wait -- tools/team_stress.py with three processes).  So a wait is short (p.spin_ticks, 0.5 ms by
+    // did place hold CUs and wait -- tools/team_stress.py with three processes).  So a wait is short (P()->spin_ticks, 0.5 ms by
     // default: a healthy one is microseconds): the wave that runs out of time stores this launch's identity in the abort
     // word, every wave sees it at its next wait or chunk and leaves, the CUs are free again, and the host has ALREADY queued
     // the same exec on the two-launch path behind this kernel, gated on that word (hssfsst.hip launch_core128): the features
     // are then simply computed there.  No error, no result of this kernel is kept.
     auto aborted = [&]() -> bool {
-        return __hip_atomic_load(p.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.launch;
+        return __hip_atomic_load(P()->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P()->launch;
     };
     auto gave_up = [&](unsigned) {
         if (lane == 0) {
-            __hip_atomic_store(p.abort_word, p.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store((gu32*)(p.fallbacks), p.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(P()->abort_word, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32*)(P()->fallbacks), P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     auto expired = [&](unsigned since) -> bool {         // `since` = wall_clock64() when the wait began
-        return static_cast<unsigned>(wall_clock64()) - since > p.spin_ticks ||
+        return static_cast<unsigned>(wall_clock64()) - since > P()->spin_ticks ||
                __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || aborted();
     };
     if (aborted()) return;                               // (a block that starts after the launch was given up)
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         int qi = 0;
         if (lane == 0) {
             const int snap = __hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int lower = min(lower_hint, min(snap, nwork) >> p.cpc_shift);
+            const int lower = min(lower_hint, min(snap, nwork) >> P()->cpc_shift);
             __hip_atomic_store(pend + wv, lower, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         qi = __builtin_amdgcn_readfirstlane(qi);
         d_valid = false;
         while (qi < nwork) {
-            ko_d = qi >> p.cpc_shift;
+            ko_d = qi >> P()->cpc_shift;
             c_d = ((member + ko_d) & (T - 1)) + T * (qi & (cpc - 1));
             if (c_d < NC) { d_valid = true; break; }
             if (lane == 0) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -254,8 +260,8 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         if (d_valid) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
-            const float* xsig = p.x + (static_cast<long long>(team) + static_cast<long long>(ko_d) * nteams) * p.xstride;
-            const int t0 = p.col0 + c_d * (16 * kTeamGpc);
+            const float* xsig = P()->x + (static_cast<long long>(team) + static_cast<long long>(ko_d) * nteams) * P()->xstride;
+            const int t0 = P()->col0 + c_d * (16 * kTeamGpc);
 #pragma unroll
             for (int k = 0; k < SREG; ++k) {
                 const int gi = t0 + lane_o + 64 * k - NWIN / 2;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         asm volatile("" : "+v"(lane_o));
         if constexpr (CANON) {
             static_assert(!CANON || SREG == 3, "canon_land takes the aligned tile as three samples per lane");
-            tile = canon_land(sreg, reinterpret_cast<u2*>(xs), p.r2scale, p.inv_c, lane_o);
+            tile = canon_land(sreg, reinterpret_cast<u2*>(xs), P()->r2scale, P()->inv_c, lane_o);
             return;
         }
         float e2 = 0.0f;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
             if (lane_o + 64 * k < FPW + NWIN - 1) xs[lane_o + 64 * k] = sreg[k];
             e2 = fmaf(sreg[k], sreg[k], e2);             // (a sample beyond the tile belongs to the next one: harmless in a bound)
         }
-        R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+        R2 = P()->r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
         wave_sync();
     };
     draw(0x7fffffff);
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
         double acc = 0.0;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
-        const unsigned tag_prev = (p.seq << 16) | (static_cast<unsigned>(ko_prev) & 0xffffu);
+        const unsigned tag_prev = (P()->seq << 16) | (static_cast<unsigned>(ko_prev) & 0xffffu);
         const gu64* slot_prev = mail + static_cast<size_t>(ko_prev & (kTeamMailSlots - 1)) * NC * 8;
         if (xf) {
             PROBE(7);
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
             asm volatile("" : "+v"(lane_o));
             const int g = lane_o >> 4, j = lane_o & 15;
             f2* row_disp = disp_base + j * LDF;
-            const int t0 = p.col0 + grp0 * 16;
+            const int t0 = P()->col0 + grp0 * 16;
             double bsum = 0.0;                                       // lane of row q: quantity q of this chunk's block sum
             unsigned long long pf[2 * kTeamPf];
 #pragma unroll
@@ -362,8 +368,8 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 }
                 const int tg = t0 + grp * 16;
                 if constexpr (CANON) {
-                    canon_group<KLO, KC, 2>(reinterpret_cast<const u2*>(xs) + grp * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab,
-                                         tile, tiny, lane_o, p.x + b * p.xstride, n, tg
+                    canon_group<KLO, KC, 2>(reinterpret_cast<const u2*>(xs) + grp * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab,
+                                         tile, tiny, lane_o, P()->x + b * P()->xstride, n, tg
 #ifdef HSS_TEAM_PROBE
                                          , pr_c
 #endif
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 int f_dirty = flag[0];
                 const int f_ties = flag[1];
                 if (__builtin_amdgcn_readfirstlane(f_ties) != 0) {
-                    resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, RQ * (s1 + 1), p.wtab, p.twtab, lane_o);
+                    resolve_ties<NWIN>(tq, xs + grp * 16, disp_base, LDF, flag, klo, K, own_base, OLD, RQ * s0, RQ * (s1 + 1), P()->wtab, P()->twtab, lane_o);
                     wave_sync();
                     f_dirty = flag[0];
                 }
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
             //      publish the chunk's block sum: lanes 16 q and 16 q + 1 hold quantity q; word {tag, upper | lower half}
             land();
             {
-                const unsigned tag = (p.seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
+                const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
                 gu64* slot = mail + (static_cast<size_t>(ko_cur & (kTeamMailSlots - 1)) * NC + c_cur) * 8;
                 const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(bsum));
                 if ((lane_o & 15) < 2) {
@@ -609,34 +615,48 @@ __global__ __launch_bounds__(64 * kTeamWaves, 2) void fsst_team128_kernel(Team12
                 return e;
             };
             const int C = 2 * K;
-            float4* d4 = reinterpret_cast<float4*>(p.out + (b_prev * static_cast<long long>(ncols) + grp0_prev * 16) * C) + lane_r;
+            float4* d4 = reinterpret_cast<float4*>(P()->out + (b_prev * static_cast<long long>(ncols) + grp0_prev * 16) * C) + lane_r;
             const int per = 8 * K;                       // float4 per full group
 #if !defined(HSS_TEAM_ABLATE) || HSS_TEAM_ABLATE < 3
-#pragma unroll
-            for (int g = 0; g < kTeamGpc; ++g) {
-                const int lim = (g < ngrp_prev) ? min(16, ncols - (grp0_prev + g) * 16) * (K >> 1) : 0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (lane_r + 64 * i < lim) {
-                        f4 pv;
-                        if constexpr (CANON) pv = (g >= kTeamGpc - kTeamPark) ? park[((g - (kTeamGpc - kTeamPark)) * 3 + i) * 64 + lane_r] : prevq[i][g];
-                        else pv = f4{prev[i][4 * g], prev[i][4 * g + 1], prev[i][4 * g + 2], prev[i][4 * g + 3]};
-                        const f2 lo = zs(f2{pv.x, pv.y}, ms[i][0]);
-                        const f2 hi = zs(f2{pv.z, pv.w}, ms[i][1]);
+            auto emit = [&](int g, int i) {
+                f4 pv;
+                if constexpr (CANON) pv = (g >= kTeamGpc - kTeamPark) ? park[((g - (kTeamGpc - kTeamPark)) * 3 + i) * 64 + lane_r] : prevq[i][g];
+                else pv = f4{prev[i][4 * g], prev[i][4 * g + 1], prev[i][4 * g + 2], prev[i][4 * g + 3]};
+                const f2 lo = zs(f2{pv.x, pv.y}, ms[i][0]);
+                const f2 hi = zs(f2{pv.z, pv.w}, ms[i][1]);
 #if defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 1        // development: plain stores
-                        *reinterpret_cast<f4*>(d4 + g * per + 64 * i) = f4{lo.x, lo.y, hi.x, hi.y};
+                *reinterpret_cast<f4*>(d4 + g * per + 64 * i) = f4{lo.x, lo.y, hi.x, hi.y};
 #elif defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 2      // development: the arithmetic without the stores
-                        { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
+                { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
 #elif defined(HSS_TEAM_STORE) && HSS_TEAM_STORE == 3      // development: every wave stores into one small region (L2-resident)
-                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(reinterpret_cast<float4*>(p.out) + (blockIdx.x * 8 + wv) * 1024 + lane_r + 64 * (3 * g + i)));
+                __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(reinterpret_cast<float4*>(P()->out) + (blockIdx.x * 8 + wv) * 1024 + lane_r + 64 * (3 * g + i)));
 #else
-                        __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + g * per + 64 * i));
+                __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + g * per + 64 * i));
 #endif
-                    }
+            };
+            // a chunk of four full groups -- every chunk but a signal's last -- needs one predicate per group, not three: a full
+            // group is 8 K float4s, every lane has the first (8 K / 64) of its three
+            if (__builtin_expect(CANON && ngrp_prev == kTeamGpc && (grp0_prev + kTeamGpc) * 16 <= ncols, 1)) {
+                static_for<kTeamGpc>([&](auto G) {
+                    static_for<3>([&](auto I) {
+                        constexpr int g = decltype(G)::value, i = decltype(I)::value;
+                        constexpr int full = CANON ? 8 * KC : 0;
+                        if constexpr (64 * (i + 1) <= full) emit(g, i);
+                        else if constexpr (64 * i < full) { if (lane_r + 64 * i < full) emit(g, i); }
+                    });
+                });
+            } else {
+                asm volatile("");
+#pragma unroll
+                for (int g = 0; g < kTeamGpc; ++g) {
+                    const int lim = (g < ngrp_prev) ? min(16, ncols - (grp0_prev + g) * 16) * (K >> 1) : 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (lane_r + 64 * i < lim) emit(g, i);
                 }
             }
 #else
-            if (lane_r == 0 && (CANON ? prevq[0][0].x : prev[0][0]) == 123.456f) p.out[0] = ms[0][0].x + ms[1][1].y;
+            if (lane_r == 0 && (CANON ? prevq[0][0].x : prev[0][0]) == 123.456f) P()->out[0] = ms[0][0].x + ms[1][1].y;
 #endif
             have_prev = false;
             PROBE(5);
