@@ -264,10 +264,12 @@ inline void core128_store_offsets(int klo, int K, int* tab /* [6][64] */, int rq
 // No queues (rounds 1-2 queued such cells, 240 + 24 per group, and fell back to float32 beyond that: tonal and offset-
 // dominated inputs under low-sidelobe windows overflowed them -- profiles/r02_adversarial_parity.txt class iii): an undecided
 // cell sets ONE BIT of a per-group bitmap in LDS, bit 16 (k' & 1) + frame of word k' >> 1, k' = 0 .. nwin/2 - 1, so their number
-// is not limited by anything and the bitmap is a sixth of the queues' size.  Resolution (resolve_bitmap): per set of 64
-// sources, up to kTieCoop cells one by one with the whole wave on one float64 DFT; more than that, lane l takes source
-// k' = l of the set and walks its 16 frame bits.  The float32 V of a cell inside the stored cover of the own plane is read
-// back from -- and cleared in -- its own column; for a cell outside it V is the float64 DFT's own result, rounded once.
+// is not limited by anything and the bitmap is a sixth of the queues' size.  Resolution (resolve_bitmap): from kTieGroup64
+// cells per 64 sources on, the whole group at once by the float64 fold + DFT factorisation (resolve_group_f64); below that, per
+// set of 64 sources, up to kTieCoop cells one by one with the whole wave on one float64 DFT, more than that lane l takes source
+// k' = l of the set and the wave walks the frames that have a bit set (one frame per round: its windowed samples are handed
+// round by v_readlane).  The float32 V of a cell inside the stored cover of the own plane is read back from -- and cleared
+// in -- its own column; for a cell outside it V is the float64 DFT's own result, rounded once.
 constexpr int kTieCoop = 6;                  // up to this many undecided cells of a 64-source set the wave resolves one by one
 __host__ __device__ constexpr int tie_words(int nwin) { return nwin / 4; }     // the bitmap (flag[1] = "some bit is set")
 constexpr float kTieMargin = 1.0f / 64.0f;   // the stay-in-row test hands |shift| > 1/2 - this to the rare path
