@@ -303,14 +303,18 @@ def bench_c3(dev, rank, world, use_dist, steps, warmup, nrec=792, T=35500, host_
         for keep in (True, False):
             first = builder.build(hrecs, keep_on_device=keep)                 # allocates the staging buffers and the arena
             torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            items = builder.build(hrecs, keep_on_device=keep, out=first.features)
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t1
+            dts = []
+            for _ in range(3):                                                # (the first timed call still faults pinned pages in)
+                t1 = time.perf_counter()
+                items = builder.build(hrecs, keep_on_device=keep, out=first.features)
+                torch.cuda.synchronize(dev)
+                dts.append(time.perf_counter() - t1)
+            dt = min(dts)
             out["device_kept" if keep else "host_returned"] = {"windows_per_s": round(len(items) / dt, 1), "seconds": round(dt, 4),
-                                                                "windows": len(items)}
+                                                                "windows": len(items), "calls_timed": len(dts),
+                                                                "seconds_each": [round(v, 4) for v in dts]}
             del items, first
-        out["note"] = (f"corpus.CorpusBuilder.build from {q} HOST recordings (pageable float32), second call of a builder (staging "
+        out["note"] = (f"corpus.CorpusBuilder.build from {q} HOST recordings (pageable float32), best of three calls of a builder after the allocating one (staging "
                        "buffers and the feature arena reused): pinned double-buffered uploads on a side stream, frame-list launches "
                        "into the arena; host-returned = group-wise D2H into a pinned host arena on a third stream")
         res["host_fed"] = out
