@@ -650,8 +650,19 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
             float4* dst4 = reinterpret_cast<float4*>(out_sig + (tg - p.col0) * (2 * K)) + lane_o;
             const int lim = nvalid * (K >> 1);
             asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+            // FUSED: the un-normalised tile is stored with AGENT scope (sc1: written through the L2 instead of staying there as
+            // dirty lines until something evicts them) -- a wave of this CU reads it back a signal later through a streaming load, by
+            // which time the L2 has long dropped it either way (profiles/r02_fused_team_variant.txt), and the final stores overwrite
+            // it.  Measured against the ordinary store, interleaved A/B, three runs: 0.2114 -> 0.2043, 0.2171 -> 0.2093, 0.2078 ->
+            // 0.2000 ms per launch (-3.5 %); sc0 sc1 the same; sc0 alone nothing; nt 16 % slower (profiles/r03_lead_ab.txt).
+            // The instruction comes from inline assembly (no builtin carries the scope bits of a 16-byte store), so the two things
+            // the compiler does for its own stores are done by hand: the wait state of the store-data hazard (s_nop), and the
+            // s_waitcnt vmcnt(0) in front of the release on the delivery counter below.
+#ifndef HSS_A_STORE_POLICY
+#define HSS_A_STORE_POLICY "sc1"
+#endif
             auto put = [&](int i) {
-                if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
+                if constexpr (FUSED) { asm volatile("global_store_dwordx4 %0, %1, off " HSS_A_STORE_POLICY "\n\ts_nop 1" :: "v"(dst4 + 64 * i), "v"(o[i]) : "memory"); }
                 else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
             };
             if (__builtin_expect(nvalid == 16, 1)) {
@@ -678,6 +689,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
     fp[0] += 1; fp[1] += fp_ta - fp_t0;
 #endif
     if constexpr (FUSED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not count the stores issued from inline assembly)
         const int sl = static_cast<int>(ksig) & 1;
         unsigned before = 0;
         if (lane == 0) before = __hip_atomic_fetch_add(done_a + sl, static_cast<unsigned>(ngrp), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
