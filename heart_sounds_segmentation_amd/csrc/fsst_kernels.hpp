@@ -375,6 +375,8 @@ __device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, B
 }
 
 // The two-kernel path: partials in HBM, [nparts][kPartFloats]; fpp = frames per piece.
+// (STRIDE: floats between consecutive pieces' partials -- kPartFloats in HBM, 6 for the copy fsst_team16_kernel keeps in LDS)
+template <int STRIDE = kPartFloats>
 __device__ __forceinline__ float4 signal_stats(const float* part, int nparts, int fpp, int ncols, int K, int lane)
 {
     const int nblocks = (nparts + kStatBlock - 1) / kStatBlock;
@@ -382,7 +384,7 @@ __device__ __forceinline__ float4 signal_stats(const float* part, int nparts, in
         double s = 0.0;
         const int g1 = min(nparts, (blk + 1) * kStatBlock);
         for (int g = blk * kStatBlock; g < g1; ++g) {
-            const float* pp = part + static_cast<long long>(g) * kPartFloats;
+            const float* pp = part + static_cast<long long>(g) * STRIDE;
             const double cnt = static_cast<double>(min(fpp, ncols - fpp * g)) * static_cast<double>(K);
             const int h = q >> 1;                        // 0 = real block, 1 = imaginary block
             s += piece_moment(q, static_cast<double>(pp[2 * h]), static_cast<double>(pp[2 * h + 1]),

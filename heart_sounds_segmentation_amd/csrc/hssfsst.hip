@@ -20,6 +20,7 @@
 #include "fsst_mfma128.hpp"
 #include "fsst_canon128.hpp"
 #include "fsst_team128.hpp"
+#include "fsst_team16.hpp"
 #include "fsst_dft.hpp"
 #include "fsst_gather.hpp"
 #include "fourier_resample.hpp"
@@ -172,6 +173,7 @@ struct hssfsst_plan {
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
     int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
+    int team16_cus = 0;                                      // ... by the 16-wave team kernel (fsst_team16.hpp)
     int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
     int zpath_pref = 0;                                      // HSSFSST_ZPATH_*: preference among the z-score paths
     int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
@@ -349,6 +351,23 @@ int ensure_status(hssfsst_plan* pl)
     return 0;
 }
 
+// Team kernels: [0] arrival counter, [1] abort word on the device; the identity of the last launch that gave up in pinned host memory.
+int ensure_team_words(hssfsst_plan* pl, hipStream_t st)
+{
+    if (pl->d_arrive) return 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), 2 * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 2 * sizeof(unsigned), st));
+    pl->arrive_total = 0;
+    void* h = nullptr;
+    HIP_TRY(hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
+    *static_cast<volatile unsigned*>(h) = 0u;
+    void* d = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+    pl->h_fallback = static_cast<volatile unsigned*>(h);
+    pl->d_fallback = static_cast<unsigned*>(d);
+    return 0;
+}
+
 // Team kernel launch (fsst_team128.hpp): nwin = 128, STACK, wide-store epilogue.  Returns 1 when it launched, 0 when
 // this exec should take another path, < 0 on error.
 template <int S1C, int KLO = -1, int KC = 0>
@@ -406,18 +425,7 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
     // is a few microseconds, a team-mate in the float64 passes can take hundreds)
     static const unsigned spin_us = std::getenv("HSSFSST_TEAM_SPIN_US") ? static_cast<unsigned>(std::atoi(std::getenv("HSSFSST_TEAM_SPIN_US"))) : 500u;
     tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
-    if (!pl->d_arrive) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), 2 * sizeof(unsigned)));
-        HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 2 * sizeof(unsigned), st));
-        pl->arrive_total = 0;
-        void* h = nullptr;
-        HIP_TRY(hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
-        *static_cast<volatile unsigned*>(h) = 0u;
-        void* d = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
-        pl->h_fallback = static_cast<volatile unsigned*>(h);
-        pl->d_fallback = static_cast<unsigned*>(d);
-    }
+    if ((rc = ensure_team_words(pl, st)) != 0) return rc;
     if (++pl->team_launch == 0u) pl->team_launch = 1u;
     tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
     static const bool force_fallback = std::getenv("HSSFSST_TEAM_FORCE_FALLBACK") != nullptr;   // tests: every team launch finds itself given up
@@ -448,6 +456,79 @@ int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t b
                 h[16] / w, h[17] / w, h[18] / w, h[19] / w, h[20] / w, h[21] / w);
     }
 #endif
+    return 1;
+}
+
+// Team kernel at four waves per SIMD (fsst_team16.hpp): canonical band, STACK, one 16-frame group per ticket, one group image
+// held in registers.  Returns 1 when it launched, 0 when this exec should take another path, < 0 on error.
+template <int KLO, int KC>
+int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    using namespace hssfsst;
+    const int G = ngroups;
+    if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
+    const size_t lds = (kCanonAtabFloats + kT16CtlFloats + static_cast<size_t>(kT16Waves) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    auto kern = fsst_team16_kernel<KLO, KC>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->team16_cus == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * kT16Waves, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->team16_cus = (per_cu >= 1 && cus >= 1) ? cus : -1;
+    }
+    if (pl->team16_cus < 1) return 0;
+    // team size: the smallest power of two that leaves a CU at most 16 groups of a signal (its 16 waves then have all of them in
+    // flight at once and the kernel's progress argument holds); HSSFSST_TEAM=n overrides upwards (A/B)
+    static const int team_env = std::getenv("HSSFSST_TEAM") ? std::atoi(std::getenv("HSSFSST_TEAM")) : 0;
+    int T = 1;
+    while (16 * T < G) T *= 2;
+    if (team_env > T) { int t2 = T; while (2 * t2 <= team_env && 2 * t2 <= G) t2 *= 2; T = t2; }
+    if (T > pl->team16_cus || T > 64) return 0;
+    int cpc = 1, cpc_shift = 0;                          // list positions per CU and signal (power of two; surplus ones are skipped)
+    while (cpc * T < G) { cpc *= 2; ++cpc_shift; }
+    if (cpc > 16 || G / T < 1) return 0;
+    const int grid = (pl->team16_cus / T) * T;
+    const int nteams = grid / T;
+    if ((batch + nteams - 1) / nteams > 65535) return 0;
+    // slots: a CU runs at most 48 list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
+    // 2 lead + 2 signals later at the earliest (fsst_team16.hpp "Progress")
+    const int lead = (48 + G / T - 1) / (G / T) + 1;         // (held + landed + drawn per wave)
+    int slots = 8;
+    while (slots < 2 * lead + 2) slots *= 2;
+    if (slots > kT16MaxSlots) return 0;
+    int rc;
+    if ((rc = ensure_status(pl)) != 0) return rc;
+    const size_t words = static_cast<size_t>(nteams) * slots * G * kT16MailWords;
+    if (words > pl->mail_cap) {
+        if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
+        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
+        pl->team_seq = 0;
+    }
+    if (++pl->team_seq > 0xffffu) {                      // tags would repeat: start over from clean mailboxes
+        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
+        pl->team_seq = 1;
+    }
+    Team16Params tp{};
+    tp.x = cp.x; tp.out = cp.out; tp.atab = pl->d_atab16; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
+    tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale_s = pl->canon_r2s; tp.inv_c = pl->canon_inv_c;
+    tp.n = cp.n; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
+    tp.team = T; tp.cpc_shift = cpc_shift; tp.slots = slots; tp.seq = pl->team_seq;
+    static const unsigned spin_us = std::getenv("HSSFSST_TEAM_SPIN_US") ? static_cast<unsigned>(std::atoi(std::getenv("HSSFSST_TEAM_SPIN_US"))) : 500u;
+    tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
+    if ((rc = ensure_team_words(pl, st)) != 0) return rc;
+    if (++pl->team_launch == 0u) pl->team_launch = 1u;
+    tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
+    static const bool force_fallback = std::getenv("HSSFSST_TEAM_FORCE_FALLBACK") != nullptr;   // tests: every team launch finds itself given up
+    if (force_fallback) {
+        HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
+    }
+    tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
+    pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * kT16Waves), lds, st, tp);
+    HIP_TRY(hipGetLastError());
     return 1;
 }
 
@@ -568,8 +649,10 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
                              : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
         // (the team kernel exists for the canonical band only -- fsst_canon128.hpp; other bands: one CU per signal or two launches)
-        if (rc == 0 && !no_team && canon16 && (col0 & 63) == 0) {
-            rc = launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st);
+        static const bool env_team8 = std::getenv("HSSFSST_TEAM8") != nullptr;         // A/B: round 3's 8-wave team kernel
+        if (rc == 0 && !no_team && canon16 && (env_team8 ? (col0 & 63) == 0 : true)) {
+            rc = env_team8 ? launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st)
+                           : launch_team16<kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st);
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
                 // them apart: fsst_team128.hpp "Giving up"): the same exec is queued behind it on the two-launch path, every
@@ -657,6 +740,27 @@ int hssfsst_dev_fuse_probe(unsigned long long* out8)
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hssfsst::g_fuse_probe), sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_fuse_probe), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
+#ifdef HSS_T16_PROBE
+int hssfsst_dev_t16_probe(unsigned long long* out16)
+{
+    unsigned long long z[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hssfsst::g_t16_probe), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_probe), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+#ifdef HSS_T16_DEBUG
+int hssfsst_dev_t16_dbg(unsigned* out64)
+{
+    unsigned z[128] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(hssfsst::g_t16_dbg), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_dbg), z, sizeof(z)) != hipSuccess) return -1;
     return 0;
 }
 #endif
