@@ -47,9 +47,9 @@ def csrc_digest():
 
 def pmc_profile(kernel_substr):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
-    (profiles/r03_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
+    (profiles/r04_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
     MI355X guide prescribes).  None when the file is absent or was measured on other sources."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -441,21 +441,19 @@ def main():
         alg = BYTES_PER_WINDOW * B
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         step_gbs = alg / (ms_per_step * 1e-3) / 1e9
-        # (the canonical band runs the kernels of csrc/fsst_canon128.hpp; HSSFSST_NO_CANON=1 -- A/B -- the general ones)
-        if os.environ.get("HSSFSST_NO_CANON"):
-            kname = {1: "fsst_core128_kernel<16, 8, 64, true, 16, 3, true>", 2: "fsst_team128_kernel<3, -1, 0>"}.get(fused, "fsst_core128_kernel<16, 8, 64, true, 16, 3, false>")
-        else:
-            kname = {1: "fsst_canon_kernel<4, 22, true>", 2: "fsst_team128_kernel<3, 4, 22>"}.get(fused, "fsst_canon_kernel<4, 22, false>")
+        # which kernel ran: asked of the library (hssfsst_plan_last_kernel), not assumed
+        klong = tf.last_kernel(local)
+        kname = klong.split(" [")[0].split(" teams of")[0]
         kdesc = {1: " (transform + z-score in one launch: one CU per signal, tile round-trips through HBM inside the launch)",
-                 2: " (transform + z-score in one launch: teams of CUs, features z-scored in registers and written once)"}.get(
+                 2: " (transform + z-score in one launch: teams of CUs, four waves per SIMD, features z-scored in registers and written once)"}.get(
                      fused, " (transform; z-score is a second kernel)")
         prof = pmc_profile(kname) if B == 1024 else None
         live = live_traffic(kname, B) if (world == 1 and not args.no_extras) else None
         traffic = live["hbm_bytes_per_launch"] if live else (prof.get("hbm_bytes_per_launch") if prof else None)
-        roof = {"bound": "hbm", "kernel": kname + kdesc,
+        roof = {"bound": "hbm", "kernel": kname + kdesc, "launch": klong,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_source": (live["how"] if live else ("profiles/r03_pmc.json (same sources, SHA-256 checked)" if prof else None)),
+                "traffic_source": (live["how"] if live else ("profiles/r04_pmc.json (same sources, SHA-256 checked)" if prof else None)),
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom_ms, 4),
                 "other_kernels_avg_ms": round(norm_ms / max(ncalls, 1), 4), "launches_timed": ncalls,
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
@@ -469,15 +467,15 @@ def main():
                 roof["mfma_f16_tflops"] = round(prof["SQ_INSTS_MFMA"] * MFMA_F16_FLOP / (dom_ms * 1e-3) / 1e12, 2)
                 roof["fp32_note"] = (f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) per launch, "
                                      f"peak {FP32_PEAK_TFLOPS} TFLOP/s; besides {int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x32_f16 x {MFMA_F16_FLOP} FLOP "
-                                     "(the window fold with split operands: 4 half products per real one) on the 16-bit matrix pipe (profiles/r03_pmc.json)")
+                                     "(the window fold with split operands: 4 half products per real one) on the 16-bit matrix pipe (profiles/r04_pmc.json)")
             else:
                 roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
                                      f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
-                                     f"per launch (profiles/r03_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
-        # the same workload on the team kernel (every feature written once: algorithmic HBM traffic), beside the default path
-        if world == 1 and not args.no_extras and fused == 1 and not os.environ.get("HSSFSST_NO_CANON"):
+                                     f"per launch (profiles/r04_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
+        # the same workload on the other single-launch kernel (one CU per signal: the tile round-trips through HBM), beside the default
+        if world == 1 and not args.no_extras and fused == 2 and not os.environ.get("HSSFSST_NO_CANON"):
             try:
-                tf.set_zpath("team", local)
+                tf.set_zpath("one_cu", local)
                 for _ in range(50):
                     tf.batch(X, out=out)
                 torch.cuda.synchronize(dev)
@@ -487,18 +485,21 @@ def main():
                 t_ms, _, t_n = tf.timing(local)
                 tf.set_timing(False, local)
                 t_path = tf.check(local)
+                o_name = tf.last_kernel(local).split(" [")[0]
                 tf.set_zpath("auto", local)
-                if t_path == 2 and t_n > 0:
-                    tl = live_traffic("fsst_team128_kernel<3, 4, 22>", B, extra_env={"HSSFSST_TEAM_ONLY": "1"})
+                if t_path == 1 and t_n > 0:
+                    tl = live_traffic(o_name, B, extra_env={"HSSFSST_NO_TEAM": "1"})
                     t_avg = t_ms / t_n
-                    roof["team_kernel"] = {"kernel": "fsst_team128_kernel<3, 4, 22> (transform + z-score in one launch: teams of CUs, features "
-                                                     "z-scored in registers and written once; bit-identical output)",
-                                           "avg_launch_ms": round(t_avg, 4), "achieved": round(alg / (t_avg * 1e-3) / 1e9, 2),
-                                           "frac": round(alg / (t_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                           "traffic": tl["hbm_bytes_per_launch"] if tl else None,
-                                           "traffic_over_algorithmic": round(tl["hbm_bytes_per_launch"] / alg, 3) if tl else None}
+                    roof["one_cu_kernel"] = {"kernel": o_name + " (transform + z-score in one launch: one CU per signal, the un-normalised tile makes a "
+                                                                "round trip through HBM; bit-identical output)",
+                                             "avg_launch_ms": round(t_avg, 4), "achieved": round(alg / (t_avg * 1e-3) / 1e9, 2),
+                                             "frac": round(alg / (t_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                             "traffic": tl["hbm_bytes_per_launch"] if tl else None,
+                                             "traffic_over_algorithmic": round(tl["hbm_bytes_per_launch"] / alg, 3) if tl else None}
             except Exception as e:                               # never lose the bench line to the side measurement
-                roof["team_kernel"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                roof["one_cu_kernel"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if traffic:
+            roof["traffic_over_algorithmic"] = round(traffic / alg, 3)
         line = {
             "metric": "PCG windows/sec FSST (1 kHz, 2000-sample)", "value": round(value, 1),
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -120,6 +120,8 @@ def lib():
         L.hssfsst_plan_last_exec_fused.argtypes = [vp]
         L.hssfsst_plan_set_zpath.argtypes = [vp, c_int]
         L.hssfsst_plan_fallbacks.argtypes = [vp]
+        L.hssfsst_plan_last_kernel.argtypes = [vp, ctypes.c_char_p, c_int]
+        L.hssfsst_plan_last_kernel.restype = c_int
         L.hssfsst_plan_fallbacks.restype = c_int
         L.hssfsst_plan_set_zpath.restype = c_int
         L.hssfsst_plan_last_exec_fused.restype = c_int

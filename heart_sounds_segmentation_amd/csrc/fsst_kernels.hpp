@@ -340,7 +340,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off, int lane)
 // Returns {mean_re, 1/std_re, mean_im, 1/std_im} (float32, like the reference's float32 tensors; a zero variance gives
 // 1/0 = inf and the z-score (v - mean) * inf = NaN for every element, as torch's 0/0).
 // stats_finish: the part after the per-lane accumulation (lane (blk % 16, q) holds the sum of its blocks' quantity q);
-// split off so that the team kernel of fsst_team128.hpp, whose block sums arrive through HBM mailboxes, runs the very same
+// split off so that a kernel whose block sums arrive some other way runs the very same
 // instructions on the very same numbers as the two-kernel path.
 __device__ __forceinline__ float4 stats_finish(double acc, double total, int lane)
 {

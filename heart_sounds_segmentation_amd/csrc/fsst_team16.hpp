@@ -2,49 +2,65 @@
 // (/root/reference/hss/transforms/synchrosqueeze.py:78-85) applied IN REGISTERS at FOUR waves per SIMD: every feature is
 // written to HBM exactly once, already normalised (algorithmic traffic: 8 000 B in + 352 000 B out per 2000-sample window).
 //
-// Round 3 had two single-launch z-score kernels: one CU per signal (16 waves per CU, but the un-normalised tile makes a
-// round trip through HBM: 2.98x the algorithmic traffic at 85 % of the chip's streaming rate -- its own ceiling) and the team
-// kernel of fsst_team128.hpp (1.04x the traffic, but a wave held a 4-group chunk in 48 registers across the next chunk's
-// transform: 233 VGPRs = two waves per SIMD, the transform at 0.188 instead of 0.140 ms per 1024 windows).  This kernel
-// keeps the team idea and drops what made it wide:
-//   * the unit of work is ONE 16-frame group, not a 64-frame chunk.  A team of T CUs (16 T waves) shares a signal; its
-//     groups are dealt round-robin to the team's CUs, whose 16 waves draw them from a ticket counter in LDS.  With
-//     16 T >= the groups of a signal, all groups of a signal are in flight at once: a signal passes through the team in about
-//     ONE group time, so a finished group waits for its signal's statistics for about one group time, not four;
-//   * a wave therefore holds ONE group image -- three float4 per lane, 12 registers -- across exactly one further group's
-//     transform (canon_group of fsst_canon128.hpp, the arithmetic of every other canonical-band kernel: bit-identical
-//     features on every z-score path): 12 + the transform's ~105 fit the 128 registers of four waves per SIMD, and the LDS
-//     regions are those of fsst_canon_kernel;
+// The z-score needs the mean / unbiased std of a whole signal's (n, 2K) feature block before its first element can be stored.
+// Round 3 had two single-launch answers: one CU per signal (fsst_canon_kernel<.., true>: 16 waves per CU, but the un-normalised
+// tile makes a round trip through HBM -- 2.98x the algorithmic traffic at 85 % of the chip's streaming rate, its own ceiling)
+// and a team kernel whose waves held a 64-frame chunk in 48 registers across the next chunk's transform (1.04x the traffic,
+// but 233 VGPRs = two waves per SIMD: the transform at 0.188 instead of 0.140 ms per 1024 windows; removed this round).  This
+// kernel keeps the team idea and drops what made it wide:
+//   * the unit of work is ONE 16-frame group.  A team of T CUs (16 T waves) shares a signal; its groups are dealt round-robin
+//     to the team's CUs, whose 16 waves draw them from a ticket counter in LDS.  With 16 T >= twice the groups of a signal,
+//     a signal passes through the team in about one group time;
+//   * a wave holds up to DEPTH = 2 group images -- three float4 per lane and group, 24 registers -- across further groups'
+//     transforms (canon_group of fsst_canon128.hpp, the arithmetic of every other canonical-band kernel: bit-identical
+//     features on every z-score path): 24 + the transform's ~103 = 127 of the 128 registers of four waves per SIMD (the one
+//     spill, 20 bytes, sits in front of the float64 whole-group loop of the rounding-tie path -- code object checked);
+//     the LDS regions are those of fsst_canon_kernel;
 //   * a group's statistics partial (the six float32 numbers of the two-launch path) is published as six tagged 8-byte words
 //     in the team's mailbox (relaxed agent-scope atomics: no fence, no cache write-back);
-//   * the float64 part of the statistics runs ONCE per signal and CU, not once per chunk and wave: the first wave of a CU
-//     that needs a signal's statistics claims it (LDS), collects the signal's partials from the mailbox, runs the very
-//     instructions of signal_stats() (fsst_kernels.hpp) on them and leaves {mean, 1/std} x 2 in LDS for its 15 siblings.
+//   * the float64 part of the statistics runs ONCE per signal and CU: the first wave of a CU that cannot go on without a
+//     signal's statistics claims it (LDS), copies the signal's partials from the mailbox, runs the very instructions of
+//     signal_stats() (fsst_kernels.hpp) on them and leaves {mean, 1/std} x 2 in LDS for its 15 siblings.
+// What limits it (profiles/r04_team_occupancy.txt): a resolve is two trips through the memory system (the last partial
+// becoming visible, the copy) plus the sums, ~5 us against a group time of 4.5 us; with two held groups about 45 % of the
+// releases still wait.  Measured and rejected: a third held group (12 more registers: one image spills to scratch in the hot
+// loop), three waves per SIMD with four held groups (the transform loses 25 %), parking images in the free LDS, resolving
+// early (blocking or through global_load_lds copies looked at a group later), releasing in the middle of the transform.
 //
-// Progress.  A wave publishes a group before it waits for anything, and it waits only for the signal of the group it HOLDS.
-// Besides the held group it has up to two tickets it has not published yet (one landed, one drawn with its samples in flight):
-// these must never belong to the signal it waits for -- a first version drew ahead unconditionally and deadlocked as soon as a
-// wave fell behind its siblings (held group, landed group and drawn group all of ONE signal: it waited for a statistic that
+// Progress.  A wave publishes a group before it waits for anything, and it waits only for the signal of the oldest group it
+// HOLDS.  Besides the held groups it has up to two tickets it has not published yet (one landed, one drawn with its samples
+// in flight): these must never belong to a signal it may wait for -- a first version drew ahead unconditionally and deadlocked
+// as soon as a wave fell behind its siblings (held, landed and drawn group all of ONE signal: it waited for a statistic that
 // needed its own drawn group).  Hence the rule in draw(): a ticket is drawn ahead only if every position still to be handed
 // out lies in a LATER signal than the group just published; otherwise the wave draws when it has nothing landed.  Then: let a*
 // be the oldest signal of a team with an unpublished group.  A drawn-but-unpublished group of a* belongs to a wave that is
 // transforming or waits for an older -- complete -- signal: it gets published.  An undrawn one needs a free wave of its CU: if
 // all 16 were waiting they would each hold a published group of a* that precedes it in the CU's list, 17 positions of one
-// signal, but a list holds at most 16 (host-checked: cpc <= 16).  A CU cannot run more than 3 x 16 list positions ahead of its
-// oldest unresolved signal (every wave is then waiting), which bounds the mailbox / LDS slots in use (host: slots >= 2 lead + 2).
-// Every wait is bounded in wall-clock time; a wait that runs out gives the LAUNCH up (abort word) and the gated launches
-// queued behind it compute the exec (hssfsst.hip), exactly as for fsst_team128_kernel -- see there for why (co-residency with
-// other processes' kernels is not guaranteed).
+// signal, but a list holds at most 16 (host-checked: cpc <= WPB).  A CU cannot run more than (DEPTH + 3) x 16 list positions
+// ahead of its oldest unresolved signal (every wave is then waiting), which bounds the mailbox / LDS slots in use (host:
+// slots >= 2 lead + 2).
+//
+// Giving up.  Blocks of a team wait for each other, and nothing guarantees that they are resident together once other
+// processes use the GPU (DataLoader workers, /root/reference/main.py:202-218; several ranks on one device).  Two measures:
+// block identity is the ARRIVAL number (one agent-scope atomic per block), not blockIdx: the running blocks hold identities
+// 0 .. R - 1, so every team below R / T is complete whatever share of the chip the launch got; and every wait is bounded in
+// wall-clock time (0.5 ms; a healthy one is microseconds): the wave that runs out of time stores the launch's identity in an
+// abort word, every wave sees it at its next wait and leaves, and the host has ALREADY queued the same exec behind this
+// kernel, every kernel of it gated on exactly that word (hssfsst.hip launch_core128): the features are then computed there --
+// same bits, no error (hssfsst_plan_fallbacks counts).  A plan is single-stream: two launches of one plan on different
+// streams interleave their arrivals; a block that finds its identity outside the grid gives the launch up.
 #pragma once
 #include "fsst_mfma128.hpp"
 #include "fsst_canon128.hpp"
 
+#ifndef HSS_T16_TAPB
+#define HSS_T16_TAPB 2
+#endif
 namespace hssfsst {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
-constexpr int kT16Waves = 16;                // waves per block: four per SIMD, 128 VGPRs each
-constexpr int kT16MailWords = 6;              // tagged 8-byte words per group in the mailbox: S1re S2re S1im S2im p_re p_im
+constexpr int kT16MailWords = 6;             // tagged 8-byte words per group in the mailbox: S1re S2re S1im S2im p_re p_im
 constexpr int kT16MaxSlots = 128;            // statistics slots per CU / mailbox slots per team (signal ordinal mod slots)
 constexpr int kT16CtlFloats = 16 + 64 + 192 + 2 * kT16MaxSlots + 4 * kT16MaxSlots;
                                              // [0] ticket counter [1] dead [2] identity | column classes | wide-store offsets |
@@ -53,8 +69,10 @@ constexpr int kT16CtlFloats = 16 + 64 + 192 + 2 * kT16MaxSlots + 4 * kT16MaxSlot
 #ifdef HSS_T16_DEBUG
 __device__ unsigned g_t16_dbg[128];
 #endif
-#ifdef HSS_T16_PROBE     // development: shader-clock totals per phase over all waves (results valid, kernel slowed by the stamps)
+#if defined(HSS_T16_PROBE) || defined(HSS_T16_WAITS)
 __device__ unsigned long long g_t16_probe[16];
+#endif
+#ifdef HSS_T16_PROBE     // development: shader-clock totals per phase over all waves (results valid, kernel slowed by the stamps)
 #define T16P(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); pr_t[k] += now_ - pr_last; pr_last = now_; } while (0)
 #else
 #define T16P(k) do { } while (0)
@@ -73,7 +91,7 @@ struct Team16Params {
     int n, nsig, col0, ncols;
     long long xstride;
     int team;             // CUs per team (power of two)
-    int cpc_shift;        // log2 of the list positions per CU and signal (ceil(ngroups / team) rounded up to a power of two, <= 16)
+    int cpc_shift;        // log2 of the list positions per CU and signal (ceil(ngroups / team) rounded up to a power of two, <= WPB)
     int slots;            // mailbox / statistics slots (power of two <= kT16MaxSlots)
     unsigned seq;         // launch sequence number of the plan (upper half of the mailbox tags)
     unsigned spin_ticks;  // bound of a wait in 100 MHz ticks
@@ -84,11 +102,14 @@ struct Team16Params {
     unsigned launch;      // identity of this launch (never 0)
 };
 
-template <int KLO, int KC>
-__global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(Team16Params p)
+// WPB waves per block (one block per CU), DEPTH group images held per wave (registers): (16, 2) is what the library launches
+template <int KLO, int KC, int WPB, int DEPTH>
+__global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Params p)
 {
     using C = CanonCfg<KLO, KC>;
-    constexpr int WPB = kT16Waves, K = KC, ATAB = kCanonAtabFloats;
+    static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 4, "whole waves per SIMD; a ring of at most four held groups");
+    constexpr int K = KC, ATAB = kCanonAtabFloats;
+    using ull2 = unsigned long long __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = p.n;
     const int lane = threadIdx.x & 63;
@@ -113,9 +134,8 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
     if (lane < 4) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
-    for (int i = threadIdx.x; i < 2 * kT16MaxSlots; i += 64 * WPB) ready[i] = 0u;        // ready[] and claim[]
-    // Block identity = ARRIVAL number (fsst_team128.hpp: the blocks that are running hold identities 0 .. R - 1, so every team
-    // below R / T is complete whatever share of the chip this launch was given).
+    for (int i = threadIdx.x; i < 2 * kT16MaxSlots; i += 64 * WPB) ready[i] = 0u;        // ready[], claim[]
+    // Block identity = ARRIVAL number ("Giving up" above)
     if (threadIdx.x == 64)
         next_q[2] = static_cast<int>(__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base);
     if (wv == 0) {
@@ -166,6 +186,9 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
     const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     const int smask = p.slots - 1;
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * G * kT16MailWords;
+    const int nwords = G * kT16MailWords;                // tagged words per signal (even: 16-byte pairs)
+    constexpr int RND = (kFusedMaxGroups * kT16MailWords + 127) / 128;     // pairs per lane
+    static_assert(RND == 6, "six 16-byte pairs per lane cover a signal's 128 x 6 words");
 
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
@@ -204,127 +227,134 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
         }
     };
 
-    // ---- the held group: image in registers (feature units, un-normalised), waiting for its signal's statistics
-    bool h_valid = false;
-    int ko_h = 0, g_h = 0;
-    int dbg_ko_cur = 0, dbg_g_cur = 0; (void)dbg_ko_cur; (void)dbg_g_cur;
-    f4 held[3];
+    // ---- the held groups: images in registers (feature units, un-normalised), waiting for their signals' statistics
+    // (a ring: slot (h_head + i) % DEPTH holds the i-th oldest, i < h_cnt; slot indices are wave-uniform, so every access is a
+    //  branch around code that names its own registers -- no indexed moves)
+    int h_head = 0, h_cnt = 0;
+    int ko_hs[DEPTH], g_hs[DEPTH];
+    f4 held[DEPTH][3];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { ko_hs[d] = 0; g_hs[d] = 0; }
 
-    // statistics of signal ordinal ko (of this team) -> {mean_re, 1/std_re, mean_im, 1/std_im}; false = the launch was given up.
-    // The first wave of the CU that asks claims the signal and resolves it for its siblings: it copies the signal's partials
-    // from the mailbox -- lane-linear 16-byte loads (two tagged words: each word carries its own tag, so a load that is not
-    // atomic as a whole is still validated word by word), every word fetched once; a lane whose words have not all arrived
-    // asks again for those alone -- into LDS as the two-launch path's partials [G][6] and runs signal_stats() on them: the very
-    // instructions of fsst_stats_kernel on the very numbers.  The copy lives in the wave's displaced plane + flags + bitmap
-    // (contiguous, 3 088 B >= 128 groups x 24 B; all zero between groups, and zero again when the wave is done).
-    auto signal_statistics = [&](int ko, float4& st) -> bool {
+    auto stats_ready = [&](int ko) -> bool {             // the CU already has this signal's statistics
+        unsigned have = 0u;
+        if (lane == 0) have = __hip_atomic_load(ready + (ko & smask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(have)) == static_cast<unsigned>(ko) + 1u;
+    };
+    auto stats_claimed = [&](int ko) -> bool {           // ... or one of its waves is getting them
+        unsigned c = 0u;
+        if (lane == 0) c = __hip_atomic_load(claim + (ko & smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(c)) >= static_cast<unsigned>(ko) + 1u;
+    };
+    auto try_claim = [&](int ko) -> bool {
+        unsigned mine = 0u;
+        const unsigned epoch = static_cast<unsigned>(ko) + 1u;
+        if (lane == 0) mine = __hip_atomic_fetch_max(claim + (ko & smask), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch ? 1u : 0u;
+        return __builtin_amdgcn_readfirstlane(mine) != 0u;
+    };
+
+    // ---- Statistics of signal ordinal ko (of this team): {mean_re, 1/std_re, mean_im, 1/std_im}, once per signal and CU.
+    // The wave that has claimed the signal copies its partials from the mailbox -- lane-linear, every word fetched once, each
+    // 8-byte word validated by its own tag -- into LDS as the two-launch path's partials [G][6] and runs signal_stats() on them:
+    // the very instructions of fsst_stats_kernel on the very numbers.  The copy lives in the wave's displaced plane + flags +
+    // bitmap (contiguous, 3 088 B >= 128 groups x 24 B; all zero between groups, and zero again when the wave is done).
+    float* stage = reinterpret_cast<float*>(disp_base);
+    // takes the valid pairs among w[] that are still needed (bit r of `need`: pair lane + 64 r) into the copy
+    auto take_pairs = [&](const ull2 (&w)[RND], unsigned tag, unsigned& need, int lane_r) {
+#pragma unroll
+        for (int r = 0; r < RND; ++r)
+            if ((need >> r) & 1u) {
+                if (static_cast<unsigned>(w[r].x >> 32) == tag && static_cast<unsigned>(w[r].y >> 32) == tag) {
+                    reinterpret_cast<f2*>(stage)[lane_r + 64 * r] = f2{__uint_as_float(static_cast<unsigned>(w[r].x)), __uint_as_float(static_cast<unsigned>(w[r].y))};
+                    need &= ~(1u << r);
+                }
+            }
+    };
+    auto pairs_needed = [&](int lane_r) -> unsigned {
+        unsigned need = 0u;
+#pragma unroll
+        for (int r = 0; r < RND; ++r) need |= (2 * (lane_r + 64 * r) < nwords ? 1u : 0u) << r;
+        return need;
+    };
+    // the copy is complete: float64 sums, result into LDS for the siblings, the copy's region zero again
+    auto finish_resolve = [&](int ko, int lane_r) {
+        wave_sync();
+        int ncols_o = ncols, K_o = K, G_o = G;
+        asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(G_o));
+        const float4 r = signal_stats<kT16MailWords>(stage, G_o, 16, ncols_o, K_o, lane_r);
+        wave_sync();
+        for (int i = lane_r; i < (16 * C::LDF * 2 + 4 + kCanonTieWords) / 2; i += 64) reinterpret_cast<f2*>(stage)[i] = f2{0.0f, 0.0f};
+        if (lane == 0) {
+            fin[ko & smask] = r;
+            __hip_atomic_store(ready + (ko & smask), static_cast<unsigned>(ko) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_sync();
+    };
+    // the claim is this wave's: look at the mailbox until everything is there (need: what is still missing); 0 = the launch was given up
+    auto resolve_owned = [&](int ko, unsigned need, unsigned t0, int lane_r) -> int {
+        const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
+        const gu64* slot = mail + static_cast<size_t>(ko & smask) * nwords;
+        const int last = (nwords >> 1) - 1;
+        for (unsigned polls = 0;; ++polls) {
+            ull2 w[RND];
+#pragma unroll
+            for (int r = 0; r < RND; ++r) {
+                const gu64* q = slot + 2 * min(lane_r + 64 * r, last);
+                w[r].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w[r].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            take_pairs(w, tag, need, lane_r);
+            if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
+            if ((polls & 7u) == 7u && expired(t0)) {
+#ifdef HSS_T16_DEBUG
+                const unsigned miss = __builtin_popcountll(__builtin_amdgcn_ballot_w64(need != 0u));
+                if (lane == 0 && !aborted()) __hip_atomic_store((gu32*)(P()->status), (1u << 28) | (miss << 20) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+                gave_up(); return 0;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        T16P(5);
+        finish_resolve(ko, lane_r);
+        T16P(6);
+#ifdef HSS_T16_PROBE
+        pr_t[9] += 1;
+#endif
+        return 1;
+    };
+    // the statistics for a wave that cannot go on without them: a sibling's result, or this wave resolves; 0 = the launch was given up
+    auto signal_statistics = [&](int ko, float4& st) -> int {
 #if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 1      // development: nobody waits, nobody resolves (results invalid)
         st = make_float4(0.0f, 1.0f, 0.0f, 1.0f);
-        return true;
+        return 1;
 #endif
-        const int sl = ko & smask;
-        const unsigned epoch = static_cast<unsigned>(ko) + 1u;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned t0 = static_cast<unsigned>(wall_clock64());
         for (unsigned spins = 0;; ++spins) {
-            unsigned have = 0u;
-            if (lane == 0) have = __hip_atomic_load(ready + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane(have) == epoch) break;
-            unsigned mine = 0u;
-            if (spins == 0u && lane == 0) mine = __hip_atomic_fetch_max(claim + sl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch ? 1u : 0u;
-            if (__builtin_amdgcn_readfirstlane(mine) != 0u) {
-                const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
-                const gu64* slot = mail + static_cast<size_t>(sl) * G * kT16MailWords;
-                float* stage = reinterpret_cast<float*>(disp_base);
-                const int nwords = G * kT16MailWords;                                  // (even: 16-byte pairs)
-                constexpr int RND = (kFusedMaxGroups * kT16MailWords + 127) / 128;         // pairs per lane
-                unsigned need = 0u;                                                       // bit r: pair lane + 64 r still missing
-#pragma unroll
-                for (int r = 0; r < RND; ++r) need |= (2 * (lane_r + 64 * r) < nwords ? 1u : 0u) << r;
-                for (unsigned polls = 0;; ++polls) {
-                    using ull2 = unsigned long long __attribute__((ext_vector_type(2)));
-                    ull2 w[RND];
-                    const int last = (nwords >> 1) - 1;
-#pragma unroll
-                    for (int r = 0; r < RND; ++r) {
-                        const gu64* q = slot + 2 * min(lane_r + 64 * r, last);
-                        w[r].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        w[r].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int r = 0; r < RND; ++r)
-                        if ((need >> r) & 1u) {
-                            if (static_cast<unsigned>(w[r].x >> 32) == tag && static_cast<unsigned>(w[r].y >> 32) == tag) {
-                                reinterpret_cast<f2*>(stage)[lane_r + 64 * r] = f2{__uint_as_float(static_cast<unsigned>(w[r].x)), __uint_as_float(static_cast<unsigned>(w[r].y))};
-                                need &= ~(1u << r);
-                            }
-                        }
-                    if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
-                    if ((polls & 7u) == 7u && expired(t0)) {
-#ifdef HSS_T16_DEBUG
-                        const unsigned miss = __builtin_popcountll(__builtin_amdgcn_ballot_w64(need != 0u));
-                        if (!aborted() && need != 0u) {
-                            const unsigned at = atomicAdd(&g_t16_dbg[0], 1u);
-                            if (at < 15u) {
-                                int r0 = __builtin_ctz(need);
-                                g_t16_dbg[4 * at + 4] = (static_cast<unsigned>(team) << 24) | (static_cast<unsigned>(member) << 16) | static_cast<unsigned>(ko);
-                                g_t16_dbg[4 * at + 5] = static_cast<unsigned>(lane_r + 64 * r0) | (need << 16);
-                                g_t16_dbg[4 * at + 6] = static_cast<unsigned>(w[r0].x >> 32);
-                                g_t16_dbg[4 * at + 7] = tag;
-                            }
-                        }
-                        if (lane == 0 && !aborted()) __hip_atomic_store((gu32*)(P()->status), (1u << 28) | (miss << 20) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
-                        gave_up(); return false;
-                    }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-                wave_sync();
-                T16P(5);
-                int ncols_o = ncols, K_o = K, G_o = G;
-                asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(G_o));
-                const float4 r = signal_stats<kT16MailWords>(stage, G_o, 16, ncols_o, K_o, lane_r);
-                wave_sync();
-                for (int i = lane_r; i < (16 * C::LDF * 2 + 4 + kCanonTieWords) / 2; i += 64) reinterpret_cast<f2*>(stage)[i] = f2{0.0f, 0.0f};
-                if (lane == 0) {
-                    fin[sl] = r;
-                    __hip_atomic_store(ready + sl, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                wave_sync();
-                T16P(6);
-#ifdef HSS_T16_PROBE
-                pr_t[9] += 1;
-#endif
+            if (stats_ready(ko)) break;
+            if ((spins & 15u) == 0u && try_claim(ko)) {
+                if (resolve_owned(ko, pairs_needed(lane_r), t0, lane_r) == 0) return 0;
                 break;
             }
             if ((spins & 31u) == 31u && expired(t0)) {
 #ifdef HSS_T16_DEBUG
                 if (lane == 0 && !aborted() && !is_dead()) __hip_atomic_store((gu32*)(P()->status), (2u << 28) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
-                gave_up(); return false;
+                gave_up(); return 0;
             }
-            if (is_dead()) {
-#ifdef HSS_T16_DEBUG
-                if (lane == 0) {
-                    const unsigned at = atomicAdd(&g_t16_dbg[1], 1u);
-                    if (at < 20u) { g_t16_dbg[64 + 2 * at] = (static_cast<unsigned>(team) << 24) | (static_cast<unsigned>(member) << 16) | (static_cast<unsigned>(wv) << 8) | static_cast<unsigned>(ko);
-                                    g_t16_dbg[65 + 2 * at] = (static_cast<unsigned>(g_h) << 16) | (static_cast<unsigned>(dbg_ko_cur) << 8) | static_cast<unsigned>(dbg_g_cur); }
-                }
-#endif
-                return false;
-            }
+            if (is_dead()) return 0;
             __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        st = fin[sl];
+        st = fin[ko & smask];
         T16P(4);
-        return true;
+        return 1;
     };
 
-    // z-score of the held group from registers -- (v - mean) * (1 / std), two roundings, exactly as fsst_normalize_kernel -- and
-    // its 12 streaming stores
-    auto emit_held = [&](const float4& st) {
+    // z-score of a held group from registers -- (v - mean) * (1 / std), two roundings, exactly as fsst_normalize_kernel -- and
+    // its 3 streaming stores per lane
+    auto emit_held = [&](const f4 (&hv)[3], int ko_h, int g_h, const float4& st) {
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned cls = cls_lds[lane_r];
@@ -340,8 +370,8 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
         auto put = [&](int i) {
             const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
             const f2 m0 = f2{im0 ? st.z : st.x, im0 ? st.w : st.y}, m1 = f2{im1 ? st.z : st.x, im1 ? st.w : st.y};
-            const f2 lo = zs(f2{held[i].x, held[i].y}, m0);
-            const f2 hi = zs(f2{held[i].z, held[i].w}, m1);
+            const f2 lo = zs(f2{hv[i].x, hv[i].y}, m0);
+            const f2 hi = zs(f2{hv[i].z, hv[i].w}, m1);
 #if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 2      // development: the arithmetic without the stores
             { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
 #else
@@ -363,15 +393,43 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
         }
     };
 
+    // held groups leave, oldest first: every one whose signal's statistics the CU already has; the oldest is WAITED for only
+    // when the ring is full (all = true: until the ring is empty -- end of the list); false = the launch was given up
+    auto release = [&](bool all) -> bool {
+        while (h_cnt > 0) {
+            int ko_o = 0;
+            static_for<DEPTH>([&](auto S) { if (h_head == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
+            float4 st;
+            if (stats_ready(ko_o)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                st = fin[ko_o & smask];
+            } else {
+                if (!(all || h_cnt == DEPTH)) break;
+                if (signal_statistics(ko_o, st) == 0) return false;
+            }
+            static_for<DEPTH>([&](auto S) {
+                constexpr int sl = decltype(S)::value;
+                if (h_head == sl) emit_held(held[sl], ko_hs[sl], g_hs[sl], st);
+            });
+            h_head = (h_head + 1) % DEPTH;
+            --h_cnt;
+            T16P(3);
+        }
+        return true;
+    };
+
     // One loop body, in this order -- a wave's memory operations retire in order, so the ONE wait for loaded data per group
-    // (the next tile's samples) sits where everything else in flight -- the previous group's stores -- is a whole transform old:
-    //   1. transform the landed group; 2. land the drawn group's tile (its records are free: every group stages its own tile),
+    // (the next tile's samples) sits where everything else in flight -- the
+    // previous group's stores -- is a whole transform old:
+    //   1. transform the landed group;
+    //   2. land the drawn group's tile (its records are free: every group stages its own tile);
     //   3. statistics partial of the transformed group -> mailbox; draw a further group and request its samples -- IF that is
-    //      safe: the wave is about to wait for the statistics of signals up to this group's, so a ticket it holds unpublished
-    //      across those waits must belong to a later signal (the ticket counter is looked at first; positions only grow).
-    //      Otherwise the wave draws when it has nothing landed -- holding only published groups (rare: the slow path at the top);
-    //   4. the HELD group leaves (statistics of its signal: LDS, or this wave resolves them; z-score from registers, 3 stores);
-    //   5. the transformed group's image: own plane -> the held registers.
+    //      safe: a ticket the wave holds unpublished across its waits must belong to a later signal than any it may wait for
+    //      (the ticket counter is looked at first; positions only grow).  Otherwise the wave draws when it has nothing landed
+    //      -- holding only published groups (rare: the slow path at the top);
+    //   4. held groups whose statistics are there leave (z-score from registers, 3 stores each); the oldest is WAITED for only
+    //      when the ring is full;
+    //   5. the transformed group's image: own plane -> the ring's free slot.
     bool c_valid = false;                                // a group is landed: (ko, g), its tile in xrec
     int ko = 0, g = 0;
     CanonTile tile{};
@@ -395,12 +453,11 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
         asm volatile("" : "+v"(lane_o));
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
         const int tg = P()->col0 + g * 16;
-        canon_group<KLO, KC, 2>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
-                                P()->x + b * P()->xstride, n, tg);
+        canon_group<KLO, KC, HSS_T16_TAPB>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
+                                           P()->x + b * P()->xstride, n, tg);
         T16P(0);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
-        dbg_ko_cur = ko_cur; dbg_g_cur = g_cur;
         c_valid = false;
         if (d_valid) land();
         T16P(1);
@@ -410,7 +467,7 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
             f2 piv;
             const float w = canon_stats<KLO, KC>(own_base, nvalid, inv_cur, lane_o, piv);
             const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
-            gu64* e = mail + (static_cast<size_t>(ko_cur & smask) * G + g_cur) * kT16MailWords;
+            gu64* e = mail + static_cast<size_t>(ko_cur & smask) * nwords + g_cur * kT16MailWords;
             const bool odd = lane_o & 1;
             const int word = odd ? 4 + (lane_o >> 4) : (lane_o >> 4);
             const float val = odd ? ((lane_o >> 4) ? piv.y : piv.x) : w;
@@ -419,27 +476,23 @@ __global__ __launch_bounds__(64 * kT16Waves, HSS_MW128) void fsst_team16_kernel(
         }
         draw(ko_cur);
         T16P(2);
-        // ---- the held group leaves
-        if (h_valid) {
-            float4 st;
-            if (!signal_statistics(ko_h, st)) return;
-            emit_held(st);
-            T16P(3);
+        if (!release(false)) return;
+        // ---- the new group's image: own plane -> the ring's free slot (feature units)
+        {
+            const int tail = (h_head + h_cnt) % DEPTH;
+            static_for<DEPTH>([&](auto S) {
+                constexpr int sl = decltype(S)::value;
+                if (tail == sl) { canon_image<KLO, KC>(own_base, ppk_lds, inv_cur, lane_o, held[sl]); ko_hs[sl] = ko_cur; g_hs[sl] = g_cur; }
+            });
+            ++h_cnt;
         }
-        // ---- the new group's image: own plane -> registers (feature units)
-        canon_image<KLO, KC>(own_base, ppk_lds, inv_cur, lane_o, held);
         wave_sync();
-        h_valid = true; ko_h = ko_cur; g_h = g_cur;
         T16P(7);
 #ifdef HSS_T16_PROBE
         pr_t[10] += 1;
 #endif
     }
-    if (h_valid) {
-        float4 st;
-        if (!signal_statistics(ko_h, st)) return;
-        emit_held(st);
-    }
+    if (!release(true)) return;
 #ifdef HSS_T16_PROBE
     // [0] transform [1] land [2] stats + publish + draw [3] emit [4] wait (waiter, incl. resolver total) [5] resolver: poll [6] resolver: compute [7] image [8] loop top
     if (lane == 0) {

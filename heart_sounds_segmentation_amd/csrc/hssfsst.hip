@@ -19,8 +19,11 @@
 #include "fsst_kernels.hpp"
 #include "fsst_mfma128.hpp"
 #include "fsst_canon128.hpp"
-#include "fsst_team128.hpp"
 #include "fsst_team16.hpp"
+#ifndef HSS_T16_WPB
+#define HSS_T16_WPB 16
+#define HSS_T16_DEPTH 2
+#endif
 #include "fsst_dft.hpp"
 #include "fsst_gather.hpp"
 #include "fourier_resample.hpp"
@@ -172,8 +175,8 @@ struct hssfsst_plan {
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
-    int team_cus = 0;                                        // CUs usable by the team kernel (0 = not queried yet, -1 = none)
-    int team16_cus = 0;                                      // ... by the 16-wave team kernel (fsst_team16.hpp)
+    int team16_cus = 0;                                      // CUs usable by the team kernel (fsst_team16.hpp; 0 = not queried yet, -1 = none)
+    char last_kernel[112] = "";                              // the transform kernel of the last exec: instantiation, waves per block, grid (hssfsst_plan_last_kernel)
     int last_fused = 0;                                      // the last exec ran a single-launch z-score kernel
     int zpath_pref = 0;                                      // HSSFSST_ZPATH_*: preference among the z-score paths
     int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
@@ -185,6 +188,7 @@ struct hssfsst_plan {
     long long* d_starts = nullptr; size_t starts_cap = 0;    // frame-list staging (hssfsst_exec_list with host starts)
     float* d_frames = nullptr;    size_t frames_cap = 0;     // frames gathered from a list, dense [batch][n]
     int timing = 0;
+    bool timing_closed = false;   // the exec being queued has already recorded its closing kernel event (team path: right behind the team kernel)
     std::vector<hipEvent_t> ev;   // per timed exec: (before, after) per core launch + one closing event
     size_t ev_used = 0;           // events used since timing was enabled
     std::vector<int> ev_chunks;   // core launches of each timed exec
@@ -208,10 +212,21 @@ int allow_full_lds(Kern kern, int device, std::atomic<unsigned long long>& done)
     return 0;
 }
 
+// which kernel instantiation the exec that is being queued runs (hssfsst_plan_last_kernel: the dispatch made observable)
+void name_kernel(hssfsst_plan* pl, int waves, long long grid, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    const int k = vsnprintf(pl->last_kernel, sizeof(pl->last_kernel), fmt, ap);
+    va_end(ap);
+    if (k > 0 && static_cast<size_t>(k) < sizeof(pl->last_kernel))
+        snprintf(pl->last_kernel + k, sizeof(pl->last_kernel) - static_cast<size_t>(k), " [%d waves/block, grid %lld]", waves, grid);
+}
+
 int out_floats_per_sample(const hssfsst_plan* p) { return p->mode == HSSFSST_MODE_ABS ? p->K : 2 * p->K; }
 
 template <int R>
-int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblocks, hipStream_t st)
+int launch_core(hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblocks, hipStream_t st)
 {
     constexpr int NWIN = 32 * R;
     constexpr int XS = ((kTile + NWIN - 1 + 3) / 4) * 4;
@@ -229,6 +244,7 @@ int launch_core(const hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblock
     auto kern = hssfsst::fsst_core_kernel<R, kTile>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    name_kernel(pl, 1, nblocks, "fsst_core_kernel<%d, %d>", R, kTile);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kTile), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -255,6 +271,7 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     }
     int64_t blocks = nchunks;                            // small launches: one chunk per block, spread over the CUs
     if (blocks > pl->core128_slots) blocks = pl->core128_slots;
+    name_kernel(pl, WPB, blocks, "fsst_core128_kernel<%d, %d, %d, %s, %d, %d, false>", NT, RQ, kFpw128, FAST ? "true" : "false", WPB, S1C);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -300,6 +317,7 @@ int launch_fused128(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, 
     if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
+    name_kernel(pl, WPB, grid, "fsst_core128_kernel<16, 8, %d, true, %d, %d, true>", kFpw128, WPB, S1C);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -330,6 +348,7 @@ int launch_fused_general(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t ba
     if (batch < grid || rounds * grid * 100 > batch * 112) return 0;  // (as launch_fused128: a nearly full last round)
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
+    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, false, %d, %d, true>", NT, RQ, kFpw128, WPB, S1C);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -368,113 +387,25 @@ int ensure_team_words(hssfsst_plan* pl, hipStream_t st)
     return 0;
 }
 
-// Team kernel launch (fsst_team128.hpp): nwin = 128, STACK, wide-store epilogue.  Returns 1 when it launched, 0 when
-// this exec should take another path, < 0 on error.
-template <int S1C, int KLO = -1, int KC = 0>
-int launch_team128(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
-{
-    using namespace hssfsst;
-    constexpr bool CANON = KLO >= 0;
-    const int NC = (ngroups + kTeamGpc - 1) / kTeamGpc;
-    if (NC < 1 || NC > kTeamMaxChunks) return 0;
-    const size_t lds = CANON ? (kCanonAtabFloats + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
-                                (CanonCfg<(CANON ? KLO : 4), (CANON ? KC : 22)>::wave_floats() + 3 * 64 * 4 * kTeamPark)) * sizeof(float)
-                             : (core128_atab_floats(8, 16) + kTeamCtlFloats + static_cast<size_t>(kTeamWaves) *
-                                wave_lds_floats(16 * kTeamGpc, pl->klo, pl->K, 8, 16)) * sizeof(float);
-    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    auto kern = fsst_team128_kernel<S1C, KLO, KC>;
-    static std::atomic<unsigned long long> lds_ok{0};
-    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
-    if (pl->team_cus == 0) {
-        int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * kTeamWaves, lds));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
-        pl->team_cus = (per_cu >= 1 && cus >= 8) ? cus : -1;
-    }
-    if (pl->team_cus < 8) return 0;
-    // team size: the largest power of two <= min(32, chunks per signal, CUs per XCD) -- at most two chunks of a signal per CU
-    static const int team_env = std::getenv("HSSFSST_TEAM") ? std::atoi(std::getenv("HSSFSST_TEAM")) : 0;
-    int T = 1;
-    while (2 * T <= 32 && 2 * T <= NC && 8 * 2 * T <= pl->team_cus) T *= 2;
-    if (team_env > 0) { T = 1; while (2 * T <= team_env && 2 * T <= NC && 8 * 2 * T <= pl->team_cus) T *= 2; }
-    int cpc = 1, cpc_shift = 0;                          // list positions per CU and signal (power of two; surplus ones are skipped)
-    while (cpc * T < NC) { cpc *= 2; ++cpc_shift; }
-    if (cpc > 2) return 0;                               // the kernel's progress argument: a wave never holds three chunks of a signal
-    const int grid = (pl->team_cus / (8 * T)) * 8 * T;
-    const int nteams = grid / T;
-    if ((batch + nteams - 1) / nteams > 65535) return 0;
-    int rc;
-    if ((rc = ensure_status(pl)) != 0) return rc;
-    const size_t words = static_cast<size_t>(nteams) * kTeamMailSlots * NC * 8;
-    if (words > pl->mail_cap) {
-        if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
-        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
-        pl->team_seq = 0;
-    }
-    if (++pl->team_seq > 0xffffu) {                      // tags would repeat: start over from clean mailboxes
-        HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
-        pl->team_seq = 1;
-    }
-    Team128Params tp{};
-    tp.x = cp.x; tp.out = cp.out; tp.atab = cp.atab; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
-    tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale = cp.r2scale;
-    if (CANON) { tp.atab = pl->d_atab16; tp.r2scale = pl->canon_r2s; tp.inv_c = pl->canon_inv_c; }
-    tp.n = cp.n; tp.klo = cp.klo; tp.K = cp.K; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
-    tp.team = T; tp.cpc = cpc; tp.cpc_shift = cpc_shift; tp.nchunks = NC; tp.seq = pl->team_seq;
-    // how long a wave waits for its team before the launch is given up (microseconds of the 100 MHz counter; a healthy wait
-    // is a few microseconds, a team-mate in the float64 passes can take hundreds)
-    static const unsigned spin_us = std::getenv("HSSFSST_TEAM_SPIN_US") ? static_cast<unsigned>(std::atoi(std::getenv("HSSFSST_TEAM_SPIN_US"))) : 500u;
-    tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
-    if ((rc = ensure_team_words(pl, st)) != 0) return rc;
-    if (++pl->team_launch == 0u) pl->team_launch = 1u;
-    tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
-    static const bool force_fallback = std::getenv("HSSFSST_TEAM_FORCE_FALLBACK") != nullptr;   // tests: every team launch finds itself given up
-    if (force_fallback) {
-        HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
-    }
-    static const bool static_ids = std::getenv("HSSFSST_TEAM_STATIC") != nullptr;  // A/B: teams inside one XCD, no progress guarantee
-    tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total; tp.static_ids = static_ids ? 1 : 0;
-    pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
-#ifdef HSS_TEAM_PROBE
-    static unsigned long long* d_probe = nullptr;
-    static int probe_runs = 0;
-    if (!d_probe) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_probe), 32 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_probe, 0, 32 * sizeof(unsigned long long), st));
-    tp.probe = d_probe;
-#endif
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * kTeamWaves), lds, st, tp);
-    HIP_TRY(hipGetLastError());
-#ifdef HSS_TEAM_PROBE
-    if (++probe_runs % 40 == 0) {
-        unsigned long long h[32];
-        HIP_TRY(hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost));
-        const double w = static_cast<double>(h[8] ? h[8] : 1);
-        fprintf(stderr, "[team probe] waves %llu, cycles per wave: window %.0f transform %.0f publish+draw %.0f poll %.0f stats %.0f zscore+stores %.0f rest %.0f | lifetime %.0f | resolves %llu prefetched %llu ready %llu\n",
-                h[8], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[7] / w, h[6] / w, h[9], h[10], h[11]);
-        fprintf(stderr, "[team probe] transform per wave: fold %.0f fft %.0f source %.0f flags+rare %.0f stats+blocksum %.0f image %.0f\n",
-                h[16] / w, h[17] / w, h[18] / w, h[19] / w, h[20] / w, h[21] / w);
-    }
-#endif
-    return 1;
-}
-
 // Team kernel at four waves per SIMD (fsst_team16.hpp): canonical band, STACK, one 16-frame group per ticket, one group image
 // held in registers.  Returns 1 when it launched, 0 when this exec should take another path, < 0 on error.
-template <int KLO, int KC>
+template <int KLO, int KC, int WPB, int DEPTH>
 int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
 {
     using namespace hssfsst;
     const int G = ngroups;
     if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
-    const size_t lds = (kCanonAtabFloats + kT16CtlFloats + static_cast<size_t>(kT16Waves) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
+    size_t lds = (kCanonAtabFloats + kT16CtlFloats + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    auto kern = fsst_team16_kernel<KLO, KC>;
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->team16_cus == 0) {
         int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * kT16Waves, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
         pl->team16_cus = (per_cu >= 1 && cus >= 1) ? cus : -1;
     }
@@ -483,18 +414,20 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     // flight at once and the kernel's progress argument holds); HSSFSST_TEAM=n overrides upwards (A/B)
     static const int team_env = std::getenv("HSSFSST_TEAM") ? std::atoi(std::getenv("HSSFSST_TEAM")) : 0;
     int T = 1;
-    while (16 * T < G) T *= 2;
+    while ((WPB / 2) * T < G) T *= 2;                    // (cpc <= WPB is the kernel's progress argument; cpc <= WPB / 2 measured faster:
+                                                         //  a signal's groups are handed out within half a round of the CU's waves)
     if (team_env > T) { int t2 = T; while (2 * t2 <= team_env && 2 * t2 <= G) t2 *= 2; T = t2; }
     if (T > pl->team16_cus || T > 64) return 0;
     int cpc = 1, cpc_shift = 0;                          // list positions per CU and signal (power of two; surplus ones are skipped)
     while (cpc * T < G) { cpc *= 2; ++cpc_shift; }
-    if (cpc > 16 || G / T < 1) return 0;
+    if (cpc > WPB || G / T < 1) return 0;
     const int grid = (pl->team16_cus / T) * T;
     const int nteams = grid / T;
     if ((batch + nteams - 1) / nteams > 65535) return 0;
-    // slots: a CU runs at most 48 list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
+    // slots: a CU runs at most held_pos list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
     // 2 lead + 2 signals later at the earliest (fsst_team16.hpp "Progress")
-    const int lead = (48 + G / T - 1) / (G / T) + 1;         // (held + landed + drawn per wave)
+    const int held_pos = WPB * (DEPTH + 3);                  // list positions a CU's waves hold: DEPTH held + transformed + landed + drawn each
+    const int lead = (held_pos + G / T - 1) / (G / T) + 1;
     int slots = 8;
     while (slots < 2 * lead + 2) slots *= 2;
     if (slots > kT16MaxSlots) return 0;
@@ -527,7 +460,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     }
     tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
     pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * kT16Waves), lds, st, tp);
+    name_kernel(pl, WPB, grid, "fsst_team16_kernel<%d, %d, %d, %d> teams of %d", KLO, KC, WPB, DEPTH, T);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, tp);
     HIP_TRY(hipGetLastError());
     return 1;
 }
@@ -575,6 +509,7 @@ int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nch
     // (a gated launch -- the fallback behind a team launch -- almost always finds its gate closed: a quarter of the chip keeps
     //  the empty launch at ~2 us instead of ~4; when it does run, the GPU is shared anyway)
     if (pl->gate != nullptr && blocks > 64) blocks = 64;
+    if (pl->gate == nullptr) name_kernel(pl, WPB, blocks, "fsst_canon_kernel<%d, %d, false>", kCanonKlo, kCanonK);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -605,9 +540,21 @@ int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batc
     else if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
+    if (!gated) name_kernel(pl, WPB, grid, "fsst_canon_kernel<%d, %d, true>", kCanonKlo, kCanonK);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
     HIP_TRY(hipGetLastError());
     return 1;
+}
+
+int plan_next_event(hssfsst_plan* p, hipEvent_t* out_ev)
+{
+    if (p->ev.size() <= p->ev_used) {
+        hipEvent_t e2 = nullptr;
+        HIP_TRY(hipEventCreate(&e2));
+        p->ev.push_back(e2);
+    }
+    *out_ev = p->ev[p->ev_used++];
+    return 0;
 }
 
 int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* dout, float* partials, int n, int col0,
@@ -637,27 +584,28 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
     const bool canon16 = fast && nt == 16 && rq == 8 && plan_is_canon(pl) && (col0 & 15) == 0;
     if (try_fused && fast && nt == 16 && rq == 8 && pl->mode == HSSFSST_MODE_STACK) {
         const int ngroups = (ncols + 15) / 16;
-        // two single-launch z-score kernels: full batches of ~2000-sample signals take round 2's one-CU-per-signal kernel
-        // (16 waves per CU, the tile makes one HBM round trip inside the launch: 0.245 ms per 1024 windows); every other
-        // shape -- small or ragged batches, short signals -- the team kernel (8 waves per CU, features written once from
-        // registers: 0.258 ms per 1024 windows, but 1.2-1.9x faster than two launches where the former does not apply)
+        // two single-launch z-score kernels.  The team kernel (fsst_team16.hpp: features written once, from registers) is at least as
+        // fast as one CU per signal on full batches and 1.3-1.8x faster on small or ragged ones (profiles/r04_batch_sweep.txt): it
+        // goes first wherever it applies -- the canonical band, signals of at most 128 groups; one CU per signal (the tile makes a
+        // round trip through HBM inside the launch) for the other even bands of <= 24 rows, and as the team kernel's gated fallback
         static const bool env_no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;     // A/B and tests
         static const bool env_team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr; // A/B and tests
         const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
-        if (!team_only) rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
-                             : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
-        // (the team kernel exists for the canonical band only -- fsst_canon128.hpp; other bands: one CU per signal or two launches)
-        static const bool env_team8 = std::getenv("HSSFSST_TEAM8") != nullptr;         // A/B: round 3's 8-wave team kernel
-        if (rc == 0 && !no_team && canon16 && (env_team8 ? (col0 & 63) == 0 : true)) {
-            rc = env_team8 ? launch_team128<3, kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st)
-                           : launch_team16<kCanonKlo, kCanonK>(pl, cp, batch, ngroups, st);
+        if (!no_team && canon16) {
+            rc = launch_team16<kCanonKlo, kCanonK, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st);
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
-                // them apart: fsst_team128.hpp "Giving up"): the same exec is queued behind it on the two-launch path, every
-                // kernel of it gated on the abort word -- a few microseconds of empty launches when nothing went wrong
+                // them apart: fsst_team16.hpp "Progress"): the same exec is queued behind it, every kernel of it gated on the
+                // abort word -- a few microseconds of empty launches when nothing went wrong
                 pl->last_zpath = 2;
+                if (pl->timing) {                        // the kernel's own time: the closing event goes in front of the gated launches
+                    hipEvent_t evt = nullptr;
+                    if (int rce = plan_next_event(pl, &evt)) return rce;
+                    HIP_TRY(hipEventRecord(evt, st));
+                    pl->timing_closed = true;
+                }
                 pl->gate = pl->d_arrive + 1; pl->gate_val = pl->team_launch;
                 // ONE gated launch where the one-CU-per-signal kernel applies (signals of 16 .. 32 chunks; its batch
                 // conditions are about speed only): 4 us behind the team kernel instead of 11 for transform + statistics +
@@ -670,6 +618,11 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
                 *did_fuse = false;                       // (exec_impl adds the gated statistics + z-score launches)
                 return 0;
             }
+            if (rc < 0) return rc;
+        }
+        if (!team_only) {
+            rc = canon16 ? launch_canon_fused(pl, cp, batch, ngroups, st)
+                 : canon ? launch_fused128<3>(pl, cp, batch, ngroups, st) : launch_fused128<-1>(pl, cp, batch, ngroups, st);
         }
         if (rc < 0) return rc;
         if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
@@ -744,7 +697,7 @@ int hssfsst_dev_fuse_probe(unsigned long long* out8)
 }
 #endif
 
-#ifdef HSS_T16_PROBE
+#if defined(HSS_T16_PROBE) || defined(HSS_T16_WAITS)
 int hssfsst_dev_t16_probe(unsigned long long* out16)
 {
     unsigned long long z[16] = {0};
@@ -1077,6 +1030,13 @@ int hssfsst_plan_info(const hssfsst_plan* p, int* nwin, int* nf, int* klo, int* 
 
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* p) { return (p && p->last_fused) ? p->last_zpath : 0; }
 
+int hssfsst_plan_last_kernel(const hssfsst_plan* p, char* buf, int len)
+{
+    if (!p || !buf || len < 1) return fail(HSSFSST_EINVAL, "plan_last_kernel: bad argument");
+    snprintf(buf, static_cast<size_t>(len), "%s", p->last_kernel);
+    return 0;
+}
+
 int hssfsst_plan_fallbacks(hssfsst_plan* p)
 {
     if (!p) return fail(HSSFSST_EINVAL, "plan_fallbacks: plan is NULL");
@@ -1224,16 +1184,9 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         if ((rc = grow(reinterpret_cast<void**>(&p->d_stats), &p->stats_cap, static_cast<size_t>(batch) * 4, sizeof(float))) != 0) return rc;
     }
 
-    auto next_event = [&](hipEvent_t* out_ev) -> int {
-        if (p->ev.size() <= p->ev_used) {
-            hipEvent_t e2 = nullptr;
-            HIP_TRY(hipEventCreate(&e2));
-            p->ev.push_back(e2);
-        }
-        *out_ev = p->ev[p->ev_used++];
-        return 0;
-    };
+    auto next_event = [&](hipEvent_t* out_ev) -> int { return plan_next_event(p, out_ev); };
     int timed_chunks = 0;
+    p->timing_closed = false;
     // STACK: core (FP32-issue-bound) then the z-score sweep (HBM-bound, in place).  An optional
     // pipeline (HSSFSST_CHUNKS=k) cuts the batch into k chunks and runs the sweep of chunk i on a side
     // stream while the core of chunk i+1 runs on the caller's stream.  Measured on MI355X
@@ -1310,6 +1263,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             auto launch = [&](auto kern) -> int {
                 static std::atomic<unsigned long long> lds_ok{0};
                 if (int r2 = allow_full_lds(kern, p->device, lds_ok)) return r2;
+                name_kernel(p, waves, blocks, "fsst_dft_kernel<%d>", G);
                 hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * waves), per_wave * waves, st, dp);
                 return (hipGetLastError() == hipSuccess) ? 0 : fail(HSSFSST_EHIP, "exec: fsst_dft_kernel launch failed");
             };
@@ -1327,7 +1281,11 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             default: rc = fail(HSSFSST_EUNSUPPORTED, "exec: unsupported radix %d", p->R);
         }
         if (rc != 0) return rc;
-        if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); ++timed_chunks; }
+        if (p->timing) {
+            if (p->timing_closed) p->timing_closed = false;
+            else { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
+            ++timed_chunks;
+        }
         const unsigned* gate = p->gate;                  // non-null: a team launch went first; what follows is its gated fallback
         const unsigned gate_val = p->gate_val;
         p->gate = nullptr;

@@ -263,12 +263,21 @@ class FSST:
     def check(self, device_index: Optional[int] = None) -> int:
         """Extension: waits for the device and raises ``RuntimeError`` if a kernel reported a failed internal wait
         (the library also reports it at the start of the plan's next call, without being asked).  Returns the path of
-        the plan's last ``stack`` call: 0 = two launches, 1 = the one-CU-per-signal z-score kernel (full batches),
-        2 = the team kernel (features normalised in registers, written once); truthy = a single launch."""
+        the plan's last ``stack`` call: 0 = two launches, 1 = the one-CU-per-signal z-score kernel (when preferred),
+        2 = the team kernel (features normalised in registers, written once: the default for the reference's band and
+        signals up to 2048 samples); truthy = a single launch."""
         dev = self._device_index() if device_index is None else device_index
         plan = self._plan(dev)
         _lib.check(_lib.lib().hssfsst_plan_check(plan.handle), "hssfsst_plan_check")
         return int(_lib.lib().hssfsst_plan_last_exec_fused(plan.handle))
+
+    def last_kernel(self, device_index: Optional[int] = None) -> str:
+        """Extension: the transform kernel that device's plan ran last -- ``"<instantiation> [<waves> waves/block, grid <n>]"``
+        (which of the library's kernels a window length / band / mode / shape takes is otherwise only visible in a trace)."""
+        dev = self._device_index() if device_index is None else device_index
+        buf = ctypes.create_string_buffer(160)
+        _lib.check(_lib.lib().hssfsst_plan_last_kernel(self._plan(dev).handle, buf, len(buf)), "hssfsst_plan_last_kernel")
+        return buf.value.decode()
 
     def set_zpath(self, zpath: str = "auto", device_index: Optional[int] = None) -> None:
         """Extension: preference among the z-score paths of the following ``stack`` calls on that device's plan --

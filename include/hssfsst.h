@@ -108,9 +108,15 @@ int hssfsst_plan_check(hssfsst_plan* plan);
 
 /* Which path the plan's last STACK exec took: 0 = two launches (transform, then statistics + z-score sweep: long
  * signals, other window lengths, odd or wide bands), 1 = the one-CU-per-signal kernel (full batches of 961..2048-sample
- * signals), 2 = the team kernel (every other batch of signals up to 4096 samples: features stay in registers until
- * the signal's statistics arrive from the team).  All three give bit-identical results. */
+ * signals; only when preferred or for bands the team kernel does not take), 2 = the team kernel (the reference's band,
+ * signals up to 2048 samples, any batch: features stay in registers until the signal's statistics arrive from the team).
+ * All three give bit-identical results. */
 int hssfsst_plan_last_exec_fused(const hssfsst_plan* plan);
+
+/* The dispatch made observable: the transform kernel the plan's last exec ran, as
+ * "<instantiation> [<waves> waves/block, grid <blocks>]" (NUL-terminated, truncated to len).  The kernel a given
+ * (window length, band, mode, n, batch) takes is otherwise only visible in a kernel trace. */
+int hssfsst_plan_last_kernel(const hssfsst_plan* plan, char* buf, int len);
 
 /* Preference among those paths for the plan's following STACK execs: HSSFSST_ZPATH_AUTO (default: the fastest that
  * applies), HSSFSST_ZPATH_TWO_LAUNCH, HSSFSST_ZPATH_ONE_CU (else two launches), HSSFSST_ZPATH_TEAM (else two launches).  A

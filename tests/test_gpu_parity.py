@@ -626,6 +626,10 @@ def test_zpath_preference_is_bit_identical(batch):
         path = tf.check()
         if want is not None and full_chip:
             assert path == want, (zp, path)
+            # the dispatch is observable: which instantiation ran (hssfsst_plan_last_kernel)
+            name = tf.last_kernel()
+            assert name.startswith({0: "fsst_canon_kernel<4, 22, false>", 1: "fsst_canon_kernel<4, 22, true>", 2: "fsst_team16_kernel<4, 22, 16, 2>"}[want]), name
+            assert "waves/block, grid" in name
         if ref is None:
             ref = got.clone()
         else:
@@ -655,6 +659,8 @@ def test_general_band_single_launch_zscore_is_bit_identical(oracle_mod, nwin, n,
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
         want = 1 if (batch in (256, 512) and (n * ref.shape[-1]) % 4 == 0) else 0
         assert path == want, (path, want)
+        rq = {128: 8, 256: 16, 512: 16}[nwin]
+        assert tf.last_kernel().startswith(f"fsst_core128_kernel<{32 if nwin == 512 else 16}, {rq}, 64, false, ") and tf.last_kernel().split(">")[0].endswith("true" if want else "false"), tf.last_kernel()
     assert torch.equal(got, ref)
     o, hd = oracle_mod.features(X[:3].cpu().numpy(), 1000, w, band, "stack", return_halfdist=True)
     for b in range(3):
@@ -817,13 +823,9 @@ def test_bench_c3_config_line():
 
 
 def _expected_zscore_path(n, batch):
-    """hssfsst_plan_last_exec_fused for the canonical configuration on a 256-CU device (hssfsst.hip launch_core128)."""
-    rounds = -(-batch // 256)
-    if 961 <= n <= 2048 and batch >= 256 and rounds * 256 * 100 <= batch * 112:
-        return 1                                          # one CU per signal, tile round-trips through HBM inside the launch
-    if -(-(-(-n // 16)) // 4) <= 64:
-        return 2                                          # team kernel: chunks of 4 groups, at most 64 per signal
-    return 0
+    """hssfsst_plan_last_exec_fused for the canonical configuration (hssfsst.hip launch_core128): the team kernel wherever it
+    applies -- signals of at most 128 groups of 16 frames --, two launches beyond."""
+    return 2 if -(-n // 16) <= 128 else 0
 
 
 _ZS_CHILD = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
@@ -1023,16 +1025,15 @@ def test_fork_workers(mode, want):
 
 @pytest.mark.parametrize("batch,col0", [(3, 160), (3, 192), (256, 160), (3, 167)])
 def test_stack_over_a_column_range(batch, col0):
-    """hssfsst_exec_cols in STACK mode (statistics over the requested columns only) on every z-score path -- two launches
-    (batch 3 from a column that is not a tile boundary), the team kernel (batch 3 from a tile boundary), one CU per signal
-    (batch 256) -- equals the z-score, computed in float64 by torch, of the un-normalised columns; and the columns are
+    """hssfsst_exec_cols in STACK mode (statistics over the requested columns only) -- the team kernel from a group boundary
+    that is (192) or is not (160) a tile boundary, small and full batches; two launches from any other column -- equals the z-score, computed in float64 by torch, of the un-normalised columns; and the columns are
     bit for bit those of the whole-signal transform (the canonical-band kernels stage tiles aligned in absolute columns;
     a range that does not start on a group boundary -- 167 -- runs the general kernel, which has no tile scale)."""
     X = torch.from_numpy(synth.pcg_windows(batch, 2000, seed=77)).cuda()
     tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
     cols = (col0, 1696)                                    # 106 groups: inside the fused kernel's range
     got = tf._run(X, cols=cols)
-    want_path = 1 if batch >= 256 else (2 if col0 % 64 == 0 else 0)     # (the team kernel's chunks are whole tiles)
+    want_path = 2 if col0 % 16 == 0 else 0                # (the team kernel takes any range that starts on a 16-frame group boundary)
     assert tf.check() == want_path or torch.cuda.get_device_properties(0).multi_processor_count != 256
     raw = tf.unnormalized(X, cols=cols).double()
     assert got.shape == raw.shape == (batch, 1696, 44)

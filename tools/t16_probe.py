@@ -40,6 +40,9 @@ def main():
             buf = (ctypes.c_ulonglong * 16)()
             L.hssfsst_dev_t16_probe(buf)
             wv = max(buf[12], 1)
+            if os.environ.get("T16_WAITS"):
+                print(f"   per wave: blocked {buf[0] / wv / 100:.1f} us in {buf[1] / wv:.1f} waits ({buf[0] / max(buf[1], 1) / 100:.2f} us each), found ready {buf[2] / wv:.1f} times, lifetime {buf[3] / wv / 100:.1f} us", flush=True)
+                continue
             names = ["transform", "land", "stats+publish+draw", "emit", "wait(all)", "resolver poll", "resolver compute", "image", "loop top"]
             print("   per wave (cycles): " + "  ".join(f"{nm} {buf[k] / wv:.0f}" for k, nm in enumerate(names)) +
                   f" | lifetime {buf[11] / wv:.0f} resolves/wave {buf[9] / wv:.2f} groups/wave {buf[10] / wv:.1f}", flush=True)
