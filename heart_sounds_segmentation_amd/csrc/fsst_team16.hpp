@@ -259,6 +259,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     // the very instructions of fsst_stats_kernel on the very numbers.  The copy lives in the wave's displaced plane + flags +
     // bitmap (contiguous, 3 088 B >= 128 groups x 24 B; all zero between groups, and zero again when the wave is done).
     float* stage = reinterpret_cast<float*>(disp_base);
+#ifdef HSS_T16_WAITS
+    unsigned long long wt_copy = 0, wt_sums = 0, wt_n = 0, wt_looks = 0;
+#endif
     // takes the valid pairs among w[] that are still needed (bit r of `need`: pair lane + 64 r) into the copy
     auto take_pairs = [&](const ull2 (&w)[RND], unsigned tag, unsigned& need, int lane_r) {
 #pragma unroll
@@ -281,7 +284,41 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         wave_sync();
         int ncols_o = ncols, K_o = K, G_o = G;
         asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(G_o));
-        const float4 r = signal_stats<kT16MailWords>(stage, G_o, 16, ncols_o, K_o, lane_r);
+        // signal_stats() on the copy -- its arithmetic to the letter (blocks of kStatBlock pieces summed in order, lane (blk % 16, q)
+        // over blocks blk, blk + 16, ..., stats_finish) -- with the lane's at most 2 x 4 x 3 numbers fetched from LDS up front by
+        // typed loads (through a generic pointer they were 24 dependent flat loads: most of the 1.6 us the sums took)
+        const int nblocks = (G_o + kStatBlock - 1) / kStatBlock;
+        const int q = lane_r & 3, h = q >> 1;
+        const lds_float* sp = (const lds_float*)stage;
+        float v[2][kStatBlock][3];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int pc = 0; pc < kStatBlock; ++pc) {
+                const int g = min(((lane_r >> 2) + 16 * rb) * kStatBlock + pc, G_o - 1);
+                v[rb][pc][0] = sp[g * kT16MailWords + 2 * h];
+                v[rb][pc][1] = sp[g * kT16MailWords + 2 * h + 1];
+                v[rb][pc][2] = sp[g * kT16MailWords + 4 + h];
+            }
+        double acc = 0.0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int blk = (lane_r >> 2) + 16 * rb;
+            if (blk < nblocks) {
+                double sb = 0.0;
+#pragma unroll
+                for (int pc = 0; pc < kStatBlock; ++pc) {
+                    const int g = blk * kStatBlock + pc;
+                    if (g < G_o) {
+                        const double cnt = static_cast<double>(min(16, ncols_o - 16 * g)) * static_cast<double>(K_o);
+                        sb += piece_moment(q, static_cast<double>(v[rb][pc][0]), static_cast<double>(v[rb][pc][1]), static_cast<double>(v[rb][pc][2]), cnt);
+                    }
+                }
+                acc += sb;
+            }
+        }
+        static_assert(kFusedMaxGroups <= 2 * 16 * kStatBlock, "a lane sums at most two blocks");
+        const float4 r = stats_finish(acc, static_cast<double>(K_o) * static_cast<double>(ncols_o), lane_r);
         wave_sync();
         for (int i = lane_r; i < (16 * C::LDF * 2 + 4 + kCanonTieWords) / 2; i += 64) reinterpret_cast<f2*>(stage)[i] = f2{0.0f, 0.0f};
         if (lane == 0) {
@@ -292,6 +329,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     };
     // the claim is this wave's: look at the mailbox until everything is there (need: what is still missing); 0 = the launch was given up
     auto resolve_owned = [&](int ko, unsigned need, unsigned t0, int lane_r) -> int {
+#ifdef HSS_T16_WAITS
+        const unsigned long long rw0 = wall_clock64();
+        unsigned npolls = 0;
+#endif
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
         const gu64* slot = mail + static_cast<size_t>(ko & smask) * nwords;
         const int last = (nwords >> 1) - 1;
@@ -304,6 +345,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
                 w[r].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             take_pairs(w, tag, need, lane_r);
+#ifdef HSS_T16_WAITS
+            ++npolls;
+#endif
             if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
             if ((polls & 7u) == 7u && expired(t0)) {
 #ifdef HSS_T16_DEBUG
@@ -315,7 +359,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             __builtin_amdgcn_s_sleep(16);
         }
         T16P(5);
+#ifdef HSS_T16_WAITS
+        const unsigned long long rw1 = wall_clock64();
+#endif
         finish_resolve(ko, lane_r);
+#ifdef HSS_T16_WAITS
+        wt_copy += rw1 - rw0; wt_sums += wall_clock64() - rw1; wt_n += 1; wt_looks += npolls;
+#endif
         T16P(6);
 #ifdef HSS_T16_PROBE
         pr_t[9] += 1;
@@ -324,7 +374,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     };
     // the statistics for a wave that cannot go on without them: a sibling's result, or this wave resolves; 0 = the launch was given up
     auto signal_statistics = [&](int ko, float4& st) -> int {
-#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 1      // development: nobody waits, nobody resolves (results invalid)
+#if defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2)      // development: nobody waits, nobody resolves (results invalid)
         st = make_float4(0.0f, 1.0f, 0.0f, 1.0f);
         return 1;
 #endif
@@ -493,6 +543,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
 #endif
     }
     if (!release(true)) return;
+#ifdef HSS_T16_WAITS
+    if (lane == 0 && wt_n) { atomicAdd(g_t16_probe + 4, wt_copy); atomicAdd(g_t16_probe + 5, wt_sums); atomicAdd(g_t16_probe + 6, wt_n); atomicAdd(g_t16_probe + 7, wt_looks); }
+#endif
 #ifdef HSS_T16_PROBE
     // [0] transform [1] land [2] stats + publish + draw [3] emit [4] wait (waiter, incl. resolver total) [5] resolver: poll [6] resolver: compute [7] image [8] loop top
     if (lane == 0) {

@@ -41,6 +41,8 @@ def main():
             L.hssfsst_dev_t16_probe(buf)
             wv = max(buf[12], 1)
             if os.environ.get("T16_WAITS"):
+                if buf[6]:
+                    print(f"   resolves {buf[6]}: copy {buf[4] / buf[6] / 100:.2f} us in {buf[7] / buf[6]:.2f} looks, sums {buf[5] / buf[6] / 100:.2f} us each", flush=True)
                 print(f"   per wave: blocked {buf[0] / wv / 100:.1f} us in {buf[1] / wv:.1f} waits ({buf[0] / max(buf[1], 1) / 100:.2f} us each), found ready {buf[2] / wv:.1f} times, lifetime {buf[3] / wv / 100:.1f} us", flush=True)
                 continue
             names = ["transform", "land", "stats+publish+draw", "emit", "wait(all)", "resolver poll", "resolver compute", "image", "loop top"]
