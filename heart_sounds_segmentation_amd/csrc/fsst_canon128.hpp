@@ -95,6 +95,7 @@ struct CanonTile {
     float R2s;            // error-bound scale of the tile in SCALED units (see "Rounding ties" in fsst_mfma128.hpp)
     float inv;            // 1 / (sample scale x constant scale): features = plane values x inv (a power of two)
     float r2s;            // the plan's r2scale in scaled units: R^2 = r2s x (sum of squares of scaled samples)
+    bool dcdom;           // an offset dominates the tile (tile_energy, fsst_kernels.hpp): its groups are redone in float64
 };
 
 // Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile, zero outside the signal)
@@ -102,10 +103,12 @@ struct CanonTile {
 // (max |x| <= sqrt(sum x^2) < 2^hb => |x| 2^(14 - hb) < 2^14 < 65504), which the error bound needs anyway.
 __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec, float r2scale_s, float inv_c, int lane)
 {
-    float e2 = 0.0f;
+    float e2 = 0.0f, s1 = 0.0f, cnt = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) e2 = fmaf(sreg[k], sreg[k], e2);
-    const float E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+    for (int k = 0; k < 3; ++k) { e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; cnt += (sreg[k] != 0.0f) ? 1.0f : 0.0f; }
+    // (samples that are exactly zero count as padding: the test only becomes a little more eager)
+    const TileEnergy te = tile_energy(e2, s1, cnt);
+    const float E = te.E;
     const int eb = static_cast<int>((__float_as_uint(E) >> 23) & 0xffu);          // biased exponent (0: zero / denormal tile)
     const int hb = (eb - 127 + 2) >> 1;                                             // sqrt(E) < 2^hb
     const int se = (eb == 0 || eb == 255) ? 127 : 127 + 14 - hb;                    // biased exponent of the sample scale
@@ -114,6 +117,7 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
     t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
     t.R2s = r2scale_s * (E * sx) * sx;
     t.r2s = r2scale_s;
+    t.dcdom = te.dcdom;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float v = sreg[k] * sx;
@@ -283,6 +287,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         const float R2g = tile.r2s * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
         exact = __builtin_amdgcn_ballot_w64(mx > kExactTheta2 * R2g) == 0ull && R2g > 0.0f;
     }
+    if (__builtin_expect(tile.dcdom, 0)) exact = true;
 #endif
     if (__builtin_expect(exact, 0)) {
         for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
@@ -325,7 +330,9 @@ __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, flo
     //  compare and two selects, with it only the one row group that is partial across lanes)
     const int g = (lane_o >> 4) & 3, j = lane_o & 15;
     const f2* src = own_base + j * C::LD + C::KOFF + g;
-    const f2 piv = own_base[C::KOFF];                    // frame 0, row KLO: one address, broadcast
+    // (pivot: median of frame 0's first, middle and last kept row -- pivot_med3, fsst_kernels.hpp; three broadcast reads)
+    const f2 pv0 = own_base[C::KOFF], pv1 = own_base[C::KOFF + KC / 2], pv2 = own_base[C::KOFF + KC - 1];
+    const f2 piv = f2{pivot_med3(pv0.x, pv1.x, pv2.x), pivot_med3(pv0.y, pv1.y, pv2.y)};
     constexpr int NU = (KC + 3) / 4, UF = KC / 4;        // rows g + 4 u: u < UF valid in every lane group, u == UF for g < KC - 4 UF
     f2 v[NU];
 #pragma unroll

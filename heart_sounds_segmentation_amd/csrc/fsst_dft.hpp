@@ -95,14 +95,16 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
         const int tg = p.col0 + tidx * F, tr = tidx * F;
         const float* xsig = p.x + b * p.xstride;
         // stage the zero-padded tile xs[i] = xpad[tg + i] = x[tg + i - m]; sum x^2 for the error bound of displaced cells
-        float e2 = 0.0f;
+        float e2 = 0.0f, s1 = 0.0f, cnt = 0.0f;
         for (int i = lane; i < XS; i += 64) {
             const int gi = tg + i - m;
-            const float v = (i < F + N - 1 && gi >= 0 && gi < p.n) ? xsig[gi] : 0.0f;
+            const bool in = (i < F + N - 1 && gi >= 0 && gi < p.n);
+            const float v = in ? xsig[gi] : 0.0f;
             xs[i] = v;
-            e2 = fmaf(v, v, e2);
+            e2 = fmaf(v, v, e2); s1 += v; cnt += in ? 1.0f : 0.0f;
         }
-        const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+        const TileEnergy te = tile_energy(e2, s1, cnt);
+        const float R2 = p.r2scale * te.E;
         for (int i = lane; i < F * LDP; i += 64) plane[i] = f2{0.0f, 0.0f};
         wave_sync();
 
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
             float mxc = 0.0f;
             for (int i = lane; i < F * LDP; i += 64) { const f2 v = plane[i]; mxc = fmaxf(mxc, fmaf(v.x, v.x, v.y * v.y)); }
             const bool quiet = __builtin_amdgcn_ballot_w64(mxc > kExactTheta2 * R2) == 0ull && R2 > 0.0f;
-            if (quiet || q_all > kDftTieQueue) {
+            if (quiet || (te.dcdom && R2 > 0.0f) || q_all > kDftTieQueue) {      // (te.dcdom: an offset with little on top, fsst_kernels.hpp)
                 wave_sync();
                 for (int i = lane; i < F * LDP; i += 64) plane[i] = f2{0.0f, 0.0f};
                 wave_sync();
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(512) void fsst_dft_kernel(DftParams p)
             } else {
                 const int C = 2 * K;
                 float* dst = p.out + (b * static_cast<long long>(p.ncols) + trq) * C;
-                const f2 piv = pl[0];                            // statistics pivot: the group's frame 0, row klo
+                const f2 piv = f2{pivot_med3(pl[0].x, pl[K >> 1].x, pl[K - 1].x), pivot_med3(pl[0].y, pl[K >> 1].y, pl[K - 1].y)};   // pivot_med3 of the group's frame 0
                 float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
                 for (int e = lane; e < nvalid * C; e += 64) {
                     const int jj = e / C, c = e - jj * C;

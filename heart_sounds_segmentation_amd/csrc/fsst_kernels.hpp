@@ -413,6 +413,14 @@ __device__ __forceinline__ float piece_sums(float s_re, float q_re, float s_im, 
     return w;
 }
 
+// The pivot of a piece: the MEDIAN of three of its first frame's cells -- first, middle and last kept row.  A pivot only helps
+// when it lies within a few standard deviations of the piece's mean: with every row kept, a recording riding on an offset has
+// ONE row (row 0) hundreds of standard deviations away from all others; as the pivot (it was: "the piece's first cell") it
+// made sum (v - p)^2 280 x the variance sum and the float32 partials lost 2e-4 of the standard deviation (Hann(512), all rows,
+// 100 + cos: rel-L2 1.1e-4 with an EXACT transform).  The median is never the single outlier, and for a band of one or two
+// rows it is a cell of the data as before.
+__device__ __forceinline__ float pivot_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
 // Stores a piece's partial: `w` from piece_sums (rows 0..3), pivot (p_re, p_im) in every lane.
 __device__ __forceinline__ void store_partial(float* part, float w, float p_re, float p_im)
 {
@@ -421,6 +429,23 @@ __device__ __forceinline__ void store_partial(float* part, float w, float p_re, 
     const int lane = threadIdx.x & 63;
     part[lane >> 4] = w;
     part[4 + (lane & 1)] = (lane & 1) ? p_im : p_re;
+}
+
+// A staged tile's energy and whether an OFFSET dominates it.  float32 resolves a feature to ~4e-7 of its frame's spectrum norm;
+// when a tile is an offset with little on top (AC amplitude below a tenth of the mean: S1^2 >= 0.99 n E over the n samples
+// that are not zero padding) that is not 1e-4 of what the z-score makes of the small cells -- with every row kept the
+// offset's own row is the largest cell, so the "no stored cell reaches 1e-2 R" test of "Exact groups" (fsst_mfma128.hpp) does
+// not see it (profiles/r03_adversarial_parity.txt: the 8 misses of 1 800).  Such a tile's groups are redone in float64 like the
+// quiet ones.  One piece_sums for all three sums: rows 0 / 1 / 2 of the wave carry E, S1, n.
+constexpr float kDcTheta = 0.99f;
+struct TileEnergy { float E; bool dcdom; };
+__device__ __forceinline__ TileEnergy tile_energy(float e2, float s1, float cnt)
+{
+    const float w = piece_sums(e2, s1, cnt, 0.0f);
+    const float E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 0));
+    const float S1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 16));
+    const float C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 32));
+    return TileEnergy{E, E > 0.0f && S1 * S1 >= kDcTheta * C * E};
 }
 
 // Per-signal statistics from the partials: one wave per signal.
@@ -461,14 +486,17 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const float* xsig = p.x + b * p.xstride;
 
     // stage the zero-padded signal tile: xs[i] = xpad[t0 + i] = x[t0 + i - nwin/2]
-    float e2 = 0.0f;                                     // sum x^2 of the tile: error-bound scale of displaced cells
+    float e2 = 0.0f, s1 = 0.0f, cnt = 0.0f;              // sum x^2 of the tile: error-bound scale of displaced cells; sum x, samples
     for (int i = tid; i < TILE + NWIN - 1; i += TILE) {
         const int g = t0 + i - NWIN / 2;
-        const float v = (g >= 0 && g < n) ? xsig[g] : 0.0f;
+        const bool in = (g >= 0 && g < n);
+        const float v = in ? xsig[g] : 0.0f;
         xs[i] = v;
-        e2 = fmaf(v, v, e2);
+        e2 = fmaf(v, v, e2); s1 += v; cnt += in ? 1.0f : 0.0f;
     }
-    const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
+    static_assert(TILE == 64, "tile_energy reduces one wave");
+    const TileEnergy te = tile_energy(e2, s1, cnt);
+    const float R2 = p.r2scale * te.E;
     const bool oneplane = p.oneplane != 0;
     float* disp = oneplane ? own : own + 2 * K * LD;
     for (int c = 0; c < 2 * K; ++c) disp[c * LD + tid] = 0.0f;
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     {
         float mxc = 0.0f;
         for (int k = 0; k < K; ++k) { const float re = acc[k * LD + tid], im = acc[(K + k) * LD + tid]; mxc = fmaxf(mxc, fmaf(re, re, im * im)); }
-        if (__builtin_amdgcn_ballot_w64(mxc > 1.0e-4f * R2) == 0ull && R2 > 0.0f) {
+        if ((__builtin_amdgcn_ballot_w64(mxc > 1.0e-4f * R2) == 0ull || te.dcdom) && R2 > 0.0f) {
             for (int c = 0; c < 2 * K; ++c) acc[c * LD + tid] = 0.0f;
             const int klo = p.klo;
             for (int kp = 0; kp <= NWIN / 2; ++kp) {
@@ -552,7 +580,8 @@ __global__ __launch_bounds__(TILE, 2) void fsst_core_kernel(CoreParams p)
     const int dtt = TILE / C, dc = TILE - dtt * C;
     static_assert(TILE == 64, "one wave per tile: the statistics partial is a single-wave reduction");
     // pivots of this tile's statistics partial: its first frame's first kept row (a value of the data itself)
-    const float p_re = acc[0], p_im = acc[K * LD];
+    const float p_re = pivot_med3(acc[0], acc[(K >> 1) * LD], acc[(K - 1) * LD]);
+    const float p_im = pivot_med3(acc[K * LD], acc[(K + (K >> 1)) * LD], acc[(2 * K - 1) * LD]);
     float s_re = 0.0f, q_re = 0.0f, s_im = 0.0f, q_im = 0.0f;
     for (int e = tid; e < total; e += TILE) {
         float val;

@@ -1056,22 +1056,24 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         }
     } else {
     const float* xsig = p.x + b * p.xstride;
-    auto stage_tile = [&](int t0) -> float {             // xs[i] = xpad[t0 + i] = x[t0 + i - 64]; returns sum x^2 (per lane)
-        float e = 0.0f;
+    auto stage_tile = [&](int t0) -> TileEnergy {        // xs[i] = xpad[t0 + i] = x[t0 + i - 64]; the tile's energy / offset test
+        float e = 0.0f, s1 = 0.0f, cnt = 0.0f;
         int lane_t = lane;                               // (opaque per tile: the tile's lane addresses are not hoisted out of
         asm volatile("" : "+v"(lane_t));                 //  the chunk loop, held across the transform and spilled)
         for (int i = lane_t; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;
-            const float v = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
+            const bool in = (gi >= 0 && gi < n);
+            const float v = in ? xsig[gi] : 0.0f;
             xs[i] = v;
-            e = fmaf(v, v, e);
+            e = fmaf(v, v, e); s1 += v; cnt += in ? 1.0f : 0.0f;
         }
-        return e;
+        return tile_energy(e, s1, cnt);
     };
     for (int sub = 0; sub < ngrp; sub += FPW / 16) {
     const int t0 = p.col0 + (grp0 + sub) * 16;
     // R^2 of the tile's frames for the error bound of displaced cells (see "Rounding ties")
-    const float R2 = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(stage_tile(t0), 0.0f, 0.0f, 0.0f))));
+    const TileEnergy te = stage_tile(t0);
+    const float R2 = p.r2scale * te.E;
     wave_sync();
     const int gend = min(FPW / 16, ngrp - sub);
     for (int grp = 0; grp < gend; ++grp) {
@@ -1172,6 +1174,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             const float R2g = p.r2scale * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
             exact = __builtin_amdgcn_ballot_w64(mx > kExactTheta2 * R2g) == 0ull && R2g > 0.0f;
         }
+        if (te.dcdom) exact = true;                      // (an offset with little on top: tile_energy, fsst_kernels.hpp)
 #endif
         if (exact) {
             for (int i = lane_o; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
@@ -1205,10 +1208,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             }
             if (p.mode == kModeStack) {
                 // statistics partial of this group (see "Statistics" in fsst_kernels.hpp): sums of (v - pivot) and
-                // (v - pivot)^2 with the group's first cell as pivot.  Six unconditional cell reads (a row past the
+                // (v - pivot)^2 about a pivot (pivot_med3).  Six unconditional cell reads (a row past the
                 // band still lies inside this wave's LDS), then only the one row group that is partial across lanes
                 // pays for a select
-                const f2 piv = own_base[koff];               // frame 0, row klo: one address, broadcast
+                // (pivot: median of frame 0's first, middle and last kept row -- pivot_med3, fsst_kernels.hpp; broadcast reads)
+                const f2 pv0 = own_base[koff], pv1 = own_base[koff + (K >> 1)], pv2 = own_base[koff + K - 1];
+                const f2 piv = f2{pivot_med3(pv0.x, pv1.x, pv2.x), pivot_med3(pv0.y, pv1.y, pv2.y)};
                 f2 v[6];
 #pragma unroll
                 for (int u = 0; u < 6; ++u) v[u] = src[4 * u];
@@ -1277,8 +1282,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         } else {
             // lane (g, j): frame j, kept rows k = g, g + 4, g + 8 ... as packed (re, im) pairs
             const bool isabs = (p.mode == kModeAbs);
-            f2 piv = own_base[koff];                         // statistics pivot: frame 0, row klo (broadcast)
-            if (wdirty) piv += disp_base[0];
+            f2 pv0 = own_base[koff], pv1 = own_base[koff + (K >> 1)], pv2 = own_base[koff + K - 1];     // statistics pivot: pivot_med3 of frame 0
+            if (wdirty) { pv0 += disp_base[0]; pv1 += disp_base[K >> 1]; pv2 += disp_base[K - 1]; }
+            const f2 piv = f2{pivot_med3(pv0.x, pv1.x, pv2.x), pivot_med3(pv0.y, pv1.y, pv2.y)};
             f2 st_s = {0.0f, 0.0f}, st_q = {0.0f, 0.0f};
             if (j < nvalid) {
                 const int C = isabs ? K : 2 * K;

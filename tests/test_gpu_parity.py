@@ -567,13 +567,7 @@ def _adversarial_signals():
 # own row is in the band and IS the largest feature, so the group is "loud" and stays in float32), z-scored, an offset / step 100
 # times the rest: 1.1-1.9e-4 in rel-L2, one at 1.5e-4 in max -- README "Limits".  Kept as expected failures so that an
 # improvement (or a regression elsewhere) shows.
-_ADV_KNOWN = {
-    (256, "flattop", None, "stack", "step"),
-    (512, "hann", None, "stack", "big dc + tone"), (512, "blackman", None, "stack", "big dc + tone"),
-    (512, "kaiser10", None, "stack", "big dc + tone"),
-    (512, "flattop", None, "stack", "step"), (512, "flattop", None, "stack", "big dc + tone"),
-    (32, "kaiser10", (300, 450), "stack", "big dc + tone"), (32, "kaiser10", (300, 450), "raw", "big dc + tone"),     # rel-L2 1.10e-4
-}
+_ADV_KNOWN = set()
 
 
 @pytest.mark.parametrize("nwin", [32, 64, 100, 128, 256, 512])
