@@ -93,34 +93,74 @@ struct CanonCfg {
 // One tile's scale, as the kernels hand it around (wave-uniform).
 struct CanonTile {
     float R2s;            // error-bound scale of the tile in SCALED units (see "Rounding ties" in fsst_mfma128.hpp)
+    float eoff;           // != 0 with mean_s: the added offset term's own rounding, relative to |V|^2, in units of the tie bound
     float inv;            // 1 / (sample scale x constant scale): features = plane values x inv (a power of two)
     float r2s;            // the plan's r2scale in scaled units: R^2 = r2s x (sum of squares of scaled samples)
-    bool dcdom;           // an offset dominates the tile (tile_energy, fsst_kernels.hpp): its groups are redone in float64
+    float mean_s;         // != 0: the tile's mean was taken out of the records; this is it, in scaled sample units ("Offsets")
 };
 
-// Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile, zero outside the signal)
-// as records {x1 | x1 << 16, x2 | x2 << 16} and returns the scales.  The scale exponent comes from the tile's energy
-// (max |x| <= sqrt(sum x^2) < 2^hb => |x| 2^(14 - hb) < 2^14 < 65504), which the error bound needs anyway.
-__device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec, float r2scale_s, float inv_c, int lane)
+// Offsets.  float32 resolves a feature to ~4e-7 of its frame's spectrum norm.  A recording that rides on an offset (an ADC bias,
+// 1 + t, pcg + 3) has a spectrum norm that is all offset while the kept band holds its far leakage plus the content: round 3 sent
+// every such group to the float64 path (2.59 vs 0.208 ms per 1024 windows).  The transform is linear, so a tile whose mean
+// carries at least half of its energy is staged WITHOUT it (records and scale of x - mean over the samples inside the signal:
+// the fold then works at the resolution of the content) and the mean's own spectrum is added where the sources are formed:
+// (V, Vd') of a source += mean x (V, Vd') of the all-ones frame, float64 on the host (hssfsst.hip): ONE table row per source
+// for interior frames, a table of the 64 + 63 frames whose window reaches over the start / the end of the signal (both at once
+// for signals shorter than a window: ones = left + right - interior).  32 packed multiply-adds per lane and group, for such
+// tiles only.  (The mean's FOLD as the matrix instructions' C operand was tried first: its taps are as large as the offset,
+// they cancel only in the 16-point spectra -- in float32, at the offset's scale: 2.5e-4 on pcg + 100.)
+constexpr int kCanonYcFrame = 4 * 8 * 4 * 2;              // floats per frame: [lane group][stripe s][a1 | a2 | b1 | b2] as float2
+constexpr int kCanonZcFloats = kCanonYcFrame * (1 + 64 + 63);   // interior | left edge, output columns 0..63 | right edge, 0..62 samples to the end
+constexpr float kMeanTheta = 0.5f;                       // the mean is taken out when S1^2 >= kMeanTheta n E
+#ifndef HSS_OFFERR
+#define HSS_OFFERR 0.0625f
+#endif
+constexpr float kOffsetErr2 = HSS_OFFERR;                   // (5e-7 / 2e-6)^2: V = V' + mean x Yc is good to 4e-7 R' + 1.2e-7 |mean Yc|, and |mean Yc| <= |V| + R':
+                                                         // the tie bound of such a tile is tau^2 = 4e-12 (1 + |shift|)^2 (R'^2 + kOffsetErr2 |V|^2) / |V|^2
+
+// Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile that starts at output column
+// t0, zero outside the signal) as records {x1 | x1 << 16, x2 | x2 << 16} and returns the scales.  The scale exponent comes
+// from the tile's energy (max |x| <= sqrt(sum x^2) < 2^hb => |x| 2^(14 - hb) < 2^14 < 65504), which the error bound needs anyway.
+// OFFS = false (fsst_team16_kernel, which has no register to spare for the offset term): such a tile is only REPORTED -- mean_s is a
+// NaN, nothing is staged -- and the caller hands the whole exec to the kernels that have it.
+template <bool OFFS = true>
+__device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec, float r2scale_s, float inv_c, int lane, int t0, int n)
 {
     float e2 = 0.0f, s1 = 0.0f, cnt = 0.0f;
+    bool in[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; cnt += (sreg[k] != 0.0f) ? 1.0f : 0.0f; }
-    // (samples that are exactly zero count as padding: the test only becomes a little more eager)
+    for (int k = 0; k < 3; ++k) {
+        const int gi = t0 + lane + 64 * k - 64;
+        in[k] = (gi >= 0 && gi < n);
+        e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; cnt += in[k] ? 1.0f : 0.0f;
+    }
     const TileEnergy te = tile_energy(e2, s1, cnt);
-    const float E = te.E;
-    const int eb = static_cast<int>((__float_as_uint(E) >> 23) & 0xffu);          // biased exponent (0: zero / denormal tile)
+    float E = te.E, mean = 0.0f, Edc = 0.0f;
+    float x[3] = {sreg[0], sreg[1], sreg[2]};
+    if (__builtin_expect(te.E > 0.0f && te.S1 * te.S1 >= kMeanTheta * te.C * te.E, 0)) {
+        if constexpr (!OFFS) { CanonTile r{}; r.mean_s = __builtin_nanf(""); return r; }
+        mean = te.S1 / te.C;
+        float ea = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { x[k] = in[k] ? sreg[k] - mean : 0.0f; ea = fmaf(x[k], x[k], ea); }
+        E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(ea, 0.0f, 0.0f, 0.0f))));     // (recomputed: E - S1^2 / n cancels)
+        Edc = te.S1 * mean;
+    }
+    // (a tile that is nothing but its mean has E = 0: the scale then comes from the mean, whose spectrum is all there is)
+    const float Es = (E > 0.0f) ? E : Edc;
+    const int eb = static_cast<int>((__float_as_uint(Es) >> 23) & 0xffu);         // biased exponent (0: zero / denormal tile)
     const int hb = (eb - 127 + 2) >> 1;                                             // sqrt(E) < 2^hb
     const int se = (eb == 0 || eb == 255) ? 127 : 127 + 14 - hb;                    // biased exponent of the sample scale
     const float sx = __uint_as_float(static_cast<unsigned>(se) << 23);
     CanonTile t;
     t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
     t.R2s = r2scale_s * (E * sx) * sx;
+    t.eoff = (mean != 0.0f) ? kOffsetErr2 : 0.0f;
     t.r2s = r2scale_s;
-    t.dcdom = te.dcdom;
+    t.mean_s = mean * sx;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float v = sreg[k] * sx;
+        const float v = x[k] * sx;
         const _Float16 x1 = static_cast<_Float16>(v);
         const _Float16 x2 = static_cast<_Float16>(v - static_cast<float>(x1));
         const unsigned b1 = __builtin_bit_cast(unsigned short, x1), b2 = __builtin_bit_cast(unsigned short, x2);
@@ -134,7 +174,7 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
 // with the bitmap instead of the queues.  `row_disp` = this lane's frame row of the displaced plane.
 template <int KLO, int KC>
 __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigned* tb, int kpi, int j, float num, float den, f2 V,
-                                                float R2, f2* own_cell, bool stored)
+                                                float R2, float eoff, f2* own_cell, bool stored)
 {
     constexpr int NWIN = 128;
     float shift = num * __builtin_amdgcn_rcpf(den);
@@ -144,7 +184,7 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
     const float s1 = 1.0f + fabsf(shift);
     asm volatile("" : "+v"(fr));                        // (see displaced_source: keeps the two product chains unpacked)
 #ifndef HSS_NO_TIES
-    if (fr * fr * den < (kTieErr2 * kCanonErrMul) * s1 * s1 * R2 && den > kTieFloor2 * R2) {     // too close to call in float32
+    if (fr * fr * den < (kTieErr2 * kCanonErrMul) * s1 * s1 * fmaf(eoff, den, R2) && den > kTieFloor2 * R2) {     // too close to call in float32
         __hip_atomic_fetch_or(tb + (kpi >> 1), 1u << (((kpi & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         flag[1] = 1;
         return;
@@ -158,10 +198,10 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
 // rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
 // xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
 // the group's first output column, for the float64 tie path.
-template <int KLO, int KC, int TAPB = 4>
+template <int KLO, int KC, int TAPB = 4, bool OFFS = true>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
-                                            const float* xsig, int n, int tg, unsigned long long* cp = nullptr)
+                                            const float* xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
@@ -231,6 +271,26 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
     f2* row_disp = disp_base + j * C::LDF;
     float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
+    // ("Offsets" above) the lane's entries of the offset table for its frame (output column tg + j): interior, or left + right - interior
+    // (everything the offset term needs is made from the lane id INSIDE its branch, one table entry fetched and used at a time:
+    //  offsets, pointers or a stripe's four entries held across the stripes pushed this 128-register code into scratch in its
+    //  hot path)
+    const bool has_off = OFFS && tile.mean_s != 0.0f;    // (wave-uniform)
+    auto offset_term = [&](int e) -> f2 {                // mean x entry e of the lane's 32 for its frame (output column tg + j)
+        int lane_f = lane_o;
+        asm volatile("" : "+v"(lane_f));
+        const int gq = (lane_f >> 4) & 3, tf = tg + (lane_f & 15), rr = n - 1 - tf;      // frames from the start / samples to the end
+        const char* zb8 = reinterpret_cast<const char*>(zc) + 8 * e;
+        const unsigned oti = static_cast<unsigned>(gq) * 256u;
+        f2 c = *reinterpret_cast<const f2*>(zb8 + oti);
+        if (!(tg >= 64 && tg + 15 + 63 <= n - 1)) {      // (wave-uniform) a group at an end of the signal: left + right - interior
+            const unsigned otl = (tf < 64) ? oti + static_cast<unsigned>(1 + tf) * (kCanonYcFrame * 4u) : oti;
+            const unsigned otr = (rr < 63 && rr >= 0) ? oti + static_cast<unsigned>(65 + rr) * (kCanonYcFrame * 4u) : oti;
+            c = *reinterpret_cast<const f2*>(zb8 + otl) + *reinterpret_cast<const f2*>(zb8 + otr) - c;
+        }
+        float m = tile.mean_s;
+        return c * f2{m, m};
+    };
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 4
     {   f2 accz = {0.0f, 0.0f};
         static_for<NT>([&](auto I) { accz += za[decltype(I)::value] + zb[decltype(I)::value]; });
@@ -245,8 +305,14 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
         const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
         const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
-        const f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
-        const f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
+        f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
+        f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
+        if (__builtin_expect(has_off, 0)) {                  // + mean x (the all-ones frame's V, Vd' of these two sources)
+            a1 += offset_term(4 * s + 0); __builtin_amdgcn_sched_barrier(0);
+            a2 += offset_term(4 * s + 1); __builtin_amdgcn_sched_barrier(0);
+            b1 += offset_term(4 * s + 2); __builtin_amdgcn_sched_barrier(0);
+            b2 += offset_term(4 * s + 3); __builtin_amdgcn_sched_barrier(0);
+        }
         const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
         if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; mx = fmaxf(mx, dna.x); }
         if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; mx = fmaxf(mx, dnb.x); }
@@ -258,8 +324,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
-            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, cellA, STA);
-            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, cellB, STB);
+            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, tile.eoff, cellA, STA);
+            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, tile.eoff, cellB, STB);
         }
     });
     CPROBE(2);
@@ -287,7 +353,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         const float R2g = tile.r2s * __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(e2, 0.0f, 0.0f, 0.0f))));
         exact = __builtin_amdgcn_ballot_w64(mx > kExactTheta2 * R2g) == 0ull && R2g > 0.0f;
     }
-    if (__builtin_expect(tile.dcdom, 0)) exact = true;
 #endif
     if (__builtin_expect(exact, 0)) {
         for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
@@ -317,7 +382,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     CPROBE(3);
 #undef CPROBE
 }
-
 // Statistics partial of the group in the own plane (see "Statistics" in fsst_kernels.hpp): pivoted sums over the kept cells
 // of the nvalid valid frames, computed on the SCALED plane values and scaled back afterwards -- a power of two, so the
 // result is the one the unscaled cells would give.  Returns piece_sums' w (row q of the wave: S1re / S2re / S1im / S2im)
@@ -403,7 +467,7 @@ struct CanonParams {
     const float* x;       // [nsig][xstride]
     float* out;           // [nsig][ncols][2 KC]
     float* partials;      // two-launch path: [nsig][groups][kPartFloats]
-    const float* atab;    // f16 operand table (kCanonAtabFloats floats)
+    const float* atab;    // f16 operand table (kCanonAtabFloats floats), then the offset table (kCanonZcFloats floats)
     const double* wtab;   // float64 {w, dw'}[128]          } rounding-tie path
     const double* twtab;  // float64 {cos, sin}(2 pi m / 128) }
     float r2scale_s;      // r2scale of the plan x (constant scale)^2
@@ -630,12 +694,12 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
         int lane_t = lane;                               // opaque per tile / per group: nothing derived from the lane id is
         asm volatile("" : "+v"(lane_t));                 // hoisted out of these loops, held across the transform and spilled
         canon_fetch(xsig, n, tbase * 16, lane_t, sreg);
-        const CanonTile tile = canon_land(sreg, xrec, p.r2scale_s, p.inv_c, lane_t);
+        const CanonTile tile = canon_land(sreg, xrec, p.r2scale_s, p.inv_c, lane_t, tbase * 16, n);
         for (int gidx = gcur; gidx < gstop; ++gidx) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int tg = p.col0 + gidx * 16;
-            canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg);
+            canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg, p.atab + kCanonAtabFloats);
             const int nvalid = min(16, cend - tg);
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 2
             if (p.mode == 77) {

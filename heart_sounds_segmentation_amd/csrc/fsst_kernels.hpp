@@ -438,14 +438,14 @@ __device__ __forceinline__ void store_partial(float* part, float w, float p_re, 
 // not see it (profiles/r03_adversarial_parity.txt: the 8 misses of 1 800).  Such a tile's groups are redone in float64 like the
 // quiet ones.  One piece_sums for all three sums: rows 0 / 1 / 2 of the wave carry E, S1, n.
 constexpr float kDcTheta = 0.99f;
-struct TileEnergy { float E; bool dcdom; };
+struct TileEnergy { float E, S1, C; bool dcdom; };   // sum x^2, sum x, samples inside the signal; offset-dominated
 __device__ __forceinline__ TileEnergy tile_energy(float e2, float s1, float cnt)
 {
     const float w = piece_sums(e2, s1, cnt, 0.0f);
     const float E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 0));
     const float S1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 16));
     const float C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), 32));
-    return TileEnergy{E, E > 0.0f && S1 * S1 >= kDcTheta * C * E};
+    return TileEnergy{E, S1, C, E > 0.0f && S1 * S1 >= kDcTheta * C * E};
 }
 
 // Per-signal statistics from the partials: one wave per signal.

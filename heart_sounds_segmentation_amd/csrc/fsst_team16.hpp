@@ -81,7 +81,7 @@ __device__ unsigned long long g_t16_probe[16];
 struct Team16Params {
     const float* x;       // [nsig][xstride]
     float* out;           // [nsig][ncols][2 KC]
-    const float* atab;    // f16 operand table + float64 twiddles (kCanonAtabFloats floats)
+    const float* atab;    // f16 operand table + float64 twiddles (kCanonAtabFloats floats), then the offset table (kCanonZcFloats)
     const double* wtab;   // float64 {w, dw'}[128]                } rounding-tie path
     const double* twtab;  // float64 {cos, sin}(2 pi m / 128)     }
     unsigned long long* mail;   // [teams][slots][ngroups][6] tagged words {tag << 32 | float32 bits}: S1re S2re S1im S2im p_re p_im
@@ -98,7 +98,7 @@ struct Team16Params {
     unsigned* arrive;     // arrival counter of the plan (monotone over launches)
     unsigned arrive_base; // its value before this launch: block identity = arrival number - arrive_base
     unsigned* abort_word; // a wait that ran out of time stores `launch` here; every wave then leaves the kernel
-    unsigned* fallbacks;  // pinned host word: the same store, for the host's eyes
+    unsigned* fallbacks;  // pinned host words: [0] the same store, for the host's eyes; [1] the launch that gave up because of an offset tile
     unsigned launch;      // identity of this launch (never 0)
 };
 
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     auto land = [&]() {
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-        tile = canon_land(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t);
+        tile = canon_land<false>(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t, ((g_d + cg0) & ~3) * 16, n);
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
     draw(-1);
@@ -503,8 +503,14 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         asm volatile("" : "+v"(lane_o));
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
         const int tg = P()->col0 + g * 16;
-        canon_group<KLO, KC, HSS_T16_TAPB>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
-                                           P()->x + b * P()->xstride, n, tg);
+        // (a tile that rides on an offset -- fsst_canon128.hpp "Offsets" -- needs a term this kernel has no register for: the whole
+        //  exec goes to the kernels queued behind it, which have it -- same bits as on every path)
+        if (__builtin_expect(tile.mean_s != tile.mean_s, 0)) {
+            if (lane == 0) __hip_atomic_store((gu32*)(P()->fallbacks) + 1, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the reason, for the host)
+            gave_up(); return;
+        }
+        canon_group<KLO, KC, HSS_T16_TAPB, false>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
+                                           P()->x + b * P()->xstride, n, tg, P()->atab + kCanonAtabFloats);
         T16P(0);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;

@@ -174,6 +174,7 @@ struct hssfsst_plan {
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
+    unsigned seen_offset = 0; int offset_hold = 0;           // the last team launch seen to give up over an OFFSET tile; execs left that skip the team kernel
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
     int team16_cus = 0;                                      // CUs usable by the team kernel (fsst_team16.hpp; 0 = not queried yet, -1 = none)
     char last_kernel[112] = "";                              // the transform kernel of the last exec: instantiation, waves per block, grid (hssfsst_plan_last_kernel)
@@ -378,8 +379,9 @@ int ensure_team_words(hssfsst_plan* pl, hipStream_t st)
     HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 2 * sizeof(unsigned), st));
     pl->arrive_total = 0;
     void* h = nullptr;
-    HIP_TRY(hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped));
-    *static_cast<volatile unsigned*>(h) = 0u;
+    HIP_TRY(hipHostMalloc(&h, 2 * sizeof(unsigned), hipHostMallocMapped));
+    static_cast<volatile unsigned*>(h)[0] = 0u;
+    static_cast<volatile unsigned*>(h)[1] = 0u;
     void* d = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
     pl->h_fallback = static_cast<volatile unsigned*>(h);
@@ -536,7 +538,9 @@ int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batc
     if (pl->fused_slots < 1) return 0;
     int64_t grid = pl->fused_slots;
     const int64_t rounds = (batch + grid - 1) / grid;
-    if (gated) grid = batch < 64 ? batch : 64;
+    // (gated = behind a team launch: almost always the gate is closed and 64 blocks keep the empty launch short -- unless this
+    //  plan's data has been seen to ride on offsets: then the team kernel hands execs over and the fallback is the real thing)
+    if (gated) grid = (pl->seen_offset != 0u) ? (batch < grid ? batch : grid) : (batch < 64 ? batch : 64);
     else if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
@@ -593,7 +597,15 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
-        if (!no_team && canon16) {
+        // (signals that ride on an offset -- fsst_canon128.hpp "Offsets" -- make the team kernel hand the exec to the kernels behind
+        //  it; the host sees that in pinned memory an exec or two later and sends the plan's next 64 STACK execs there directly)
+        if (pl->h_fallback && !team_only) {
+            const unsigned now = pl->h_fallback[1];
+            if (now != pl->seen_offset) { pl->seen_offset = now; pl->offset_hold = 64; }
+        }
+        const bool hold = pl->offset_hold > 0 && !team_only;
+        if (hold) --pl->offset_hold;
+        if (!no_team && !hold && canon16) {
             rc = launch_team16<kCanonKlo, kCanonK, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st);
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
@@ -972,10 +984,44 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                         std::memcpy(&bits, &pick, sizeof(bits));
                         ht[(static_cast<size_t>(n) * 64 + l) * 8 + h] = bits;
                     }
+            // fsst_canon128.hpp "Offsets": what a frame of ones contributes to the (V, Vd') pairs the source stage forms.
+            //   Zc[k] = (-1)^k 0.5 sum_{m inside the signal} (w + i dw')[m] e^{-2 pi i k m / 128}  (x cs: plane units),
+            // lane group g, stripe s: source A = k 8 s + g with partner 128 - k, source B = k 8 s + (g ? 8 - g : 4) with its partner;
+            //   a1 = (P.re + X.re, P.re - X.re), a2 = (X.im - P.im, X.im + P.im)  (mix_re / mix_im of fsst_mfma128.hpp), b1, b2 alike.
+            // Frame 0 = interior (every m), 1 + t = the frame of output column t < 64 (m >= 64 - t), 65 + r = the frame r < 63 samples
+            // before the end (m <= r + 64); entry [frame][g][s][a1 | a2 | b1 | b2] as float2
+            std::vector<float> zc(static_cast<size_t>(hssfsst::kCanonZcFloats), 0.0f);
+            for (int fr = 0; fr < 1 + 64 + 63; ++fr) {
+                const int m0 = (fr >= 1 && fr <= 64) ? 64 - (fr - 1) : 0;
+                const int m1 = (fr >= 65) ? (fr - 65) + 64 : 127;
+                double zr[128], zi[128];
+                for (int k = 0; k < 128; ++k) {
+                    double re = 0.0, im = 0.0;
+                    for (int m = m0; m <= m1; ++m) {
+                        const double ang = -2.0 * M_PI * static_cast<double>((k * m) % 128) / 128.0;
+                        const double c = std::cos(ang), sn = std::sin(ang);
+                        re += window[m] * c - dwb[m] * sn;
+                        im += window[m] * sn + dwb[m] * c;
+                    }
+                    const double sg = (k & 1) ? -0.5 : 0.5;
+                    zr[k] = sg * re * cs; zi[k] = sg * im * cs;
+                }
+                for (int gg = 0; gg < 4; ++gg)
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int ks[2] = {8 * s8 + gg, 8 * s8 + (gg ? 8 - gg : 4)};
+                        float* e = zc.data() + (static_cast<size_t>(fr) * hssfsst::kCanonYcFrame) + ((gg * 8 + s8) * 4) * 2;
+                        for (int ab = 0; ab < 2; ++ab) {
+                            const int k = ks[ab], kp = (128 - k) & 127;
+                            e[4 * ab + 0] = static_cast<float>(zr[kp] + zr[k]); e[4 * ab + 1] = static_cast<float>(zr[kp] - zr[k]);     // mix_re
+                            e[4 * ab + 2] = static_cast<float>(zi[k] - zi[kp]); e[4 * ab + 3] = static_cast<float>(zi[k] + zi[kp]);     // mix_im
+                        }
+                    }
+            }
             p->canon_inv_c = static_cast<float>(std::ldexp(1.0, -sc));
             p->canon_r2s = static_cast<float>(static_cast<double>(p->r2scale) * cs * cs);
-            e = hipMalloc(reinterpret_cast<void**>(&p->d_atab16), ht.size() * sizeof(unsigned short));
+            e = hipMalloc(reinterpret_cast<void**>(&p->d_atab16), ht.size() * sizeof(unsigned short) + zc.size() * sizeof(float));
             if (e == hipSuccess) e = hipMemcpy(p->d_atab16, ht.data(), ht.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->d_atab16 + hssfsst::kCanonAtabFloats, zc.data(), zc.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
                 if (p->d_atab16) (void)hipFree(p->d_atab16);
                 (void)hipFree(p->d_atab); (void)hipFree(p->d_ctab); (void)hipFree(p->d_wtab); delete p;

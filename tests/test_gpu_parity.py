@@ -909,6 +909,36 @@ def test_dc_offset_statistics(oracle_mod, band, n, batch):
             parity.check(got[b], ref[b], hd[b], 0, what=f"dc offset band={band} [{b}]")
 
 
+@pytest.mark.parametrize("n", [2000, 1999, 190, 100, 64])
+def test_offset_signals_stay_in_float32(oracle_mod, n):
+    """Recordings that ride on an offset on the canonical band (fsst_canon128.hpp "Offsets": a tile whose mean carries half of
+    its energy is folded without it and the mean's own fold enters as the matrix instructions' C operand): a biased recording,
+    a ramp, a constant, an offset 1000 x the content -- against the oracle on every z-score path, for signals longer and
+    SHORTER than the window (190, 100, 64 samples: a frame reaches over both ends at once, left + right - interior of the
+    edge table), and with the three z-score paths still agreeing bit for bit."""
+    t = np.arange(n) / 1000.0
+    pcg = synth.pcg_windows(4, n, seed=n)
+    X = np.stack([pcg[0] + 3.0, 1.0 + t, np.full(n, 5.0), pcg[1] + 100.0, -2.5 + 0.3 * pcg[2], pcg[3] * 1e-3 + 1.0]).astype(np.float32)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    Xd = torch.from_numpy(X).cuda()
+    outs = {}
+    for zp in ("two_launch", "team", "auto"):
+        tf.set_zpath(zp)
+        outs[zp] = tf.batch(Xd).cpu().numpy()
+        tf.check()
+    assert np.array_equal(outs["two_launch"], outs["team"], equal_nan=True) and np.array_equal(outs["team"], outs["auto"], equal_nan=True)
+    ref, hd = oracle_mod.features(X, 1000, KAISER, BAND, "stack", nthreads=6, return_halfdist=True)
+    for b in range(X.shape[0]):
+        if not np.isfinite(ref[b]).all():
+            continue
+        parity.check(outs["auto"][b], ref[b], hd[b], 0, what=f"offset signal {b} n={n}")
+    raw = tf.unnormalized(Xd).cpu().numpy()
+    rr = oracle_mod.features(X, 1000, KAISER, BAND, "raw", nthreads=6)
+    for b in range(X.shape[0]):
+        un = np.concatenate([rr[b].real.T, rr[b].imag.T], axis=1)
+        assert np.abs(raw[b] - un).max() <= 1e-4 * np.abs(un).max(), (b, n)
+
+
 @pytest.mark.parametrize("N,kind", [(33, "hann"), (100, "kaiser0.5"), (127, "hamming"), (1024, "kaiser0.5"), (7, "hann"),
                                     (1000, "kaiser6"), (2, "boxcar"), (1, "boxcar"), (384, "hann")])
 def test_any_window_length(oracle_mod, N, kind):

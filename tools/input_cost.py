@@ -11,6 +11,9 @@ inputs = {
     "zeros (no cell moves)": np.zeros((1024, 2000), np.float32),
     "tone 125 Hz on-bin": np.tile(np.cos(2 * np.pi * 125.0 * t).astype(np.float32), (1024, 1)),
     "ramp+dc": np.tile((1.0 + t).astype(np.float32), (1024, 1)),
+    "pcg + 3.0": (synth.pcg_windows(1024, 2000) + 3.0).astype(np.float32),
+    "pcg + 100": (synth.pcg_windows(1024, 2000) + 100.0).astype(np.float32),
+    "constant 5": np.full((1024, 2000), 5.0, np.float32),
 }
 X0 = torch.from_numpy(inputs["pcg"]).cuda()
 for _ in range(400): tf.batch(X0, out=out)
