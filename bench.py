@@ -141,6 +141,8 @@ def self_launch(ngpus: int) -> int:
 
     import torch
     have = torch.cuda.device_count()
+    if "--dry-run-gloo" in sys.argv:
+        have = ngpus if have >= 1 else 0                   # every rank shares GPU 0; the exchange goes over gloo
     if have < ngpus:
         print(f"bench.py: --gpus {ngpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -334,6 +336,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="c2 only: skip the C3 / C5 sub-measurements and the live PMC passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # a short c2 run under rocprofv3 --pmc
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c3-recordings", type=int, default=792, help="recordings of the C3 corpus stand-in (792 = the Springer corpus' count)")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="drive the WHOLE N-rank path (self-launch, shard, C2 + C3, gathers, JSON with n_gpus = N) with every rank on GPU 0 and "
+                         "the exchange over gloo: the only thing left untested for an N-GPU box is RCCL itself.  Not a measurement.")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -357,10 +363,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+    if not args.dry_run_gloo and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         raise SystemExit(f"bench.py: --gpus {args.gpus} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.dry_run_gloo else int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("HSS_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL smoke test
     torch.cuda.set_device(local)
     if use_dist:
@@ -368,13 +374,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                timeout=datetime.timedelta(seconds=300))
+        if args.dry_run_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=300))
         world = dist.get_world_size()                      # what RCCL actually sees
     dev = torch.device("cuda", local)
 
     if args.config == "c3":
-        res = bench_c3(dev, rank, world, use_dist, max(1, min(args.steps, 20)), min(args.warmup, 3))
+        res = bench_c3(dev, rank, world, use_dist, max(1, min(args.steps, 20)), min(args.warmup, 3), nrec=args.c3_recordings)
+        if args.dry_run_gloo:
+            res["config"]["dry_run"] = "every rank on GPU 0, exchange over gloo: a path test, not a measurement"
         if rank == 0:
             print(json.dumps(res), flush=True)
         if use_dist:
@@ -518,6 +529,8 @@ def main():
         }
         if gather:
             line["allgather"] = gather
+        if args.dry_run_gloo:
+            line["config"]["dry_run"] = "every rank on GPU 0, exchange over gloo: a path test, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(Xh, w, args.cpu_budget)
     # the other BASELINE configurations of the path, carried by the same line: C3 (corpus preprocessing, recording-level
@@ -526,7 +539,7 @@ def main():
     if not args.no_extras:
         del out
         try:
-            c3 = bench_c3(dev, rank, world, use_dist, 3, 1)
+            c3 = bench_c3(dev, rank, world, use_dist, 3, 1, nrec=args.c3_recordings)
             extras["c3"] = {k: c3[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "allgather", "host_fed", "roofline") if k in c3}
         except Exception as e:                                   # never lose the bench line to a side measurement
             extras["c3"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -21,6 +21,7 @@ E_INVAL, E_NODEVICE, E_UNSUPPORTED, E_NOMEM, E_HIP = -1, -2, -3, -4, -5
 
 _lock = threading.Lock()
 _lib = None
+_fork_warned = False
 hip_owner_pid = None     # pid of the process in which this package first touched HIP (inherited by forked children)
 
 
@@ -38,13 +39,16 @@ def guard_fork() -> None:
     pid = os.getpid()
 
     def refuse(msg: str):
+        global _fork_warned
         # The reference's dataset catches RuntimeError, prints it and returns None (heart_sounds.py:183): with
         # in_memory=False and num_workers > 0 every sample of such a worker becomes None and the failure surfaces later, in
         # collate_fn.  Say it once, loudly, where it happens.
         import logging
         import warnings
-        logging.getLogger("heart_sounds_segmentation_amd").error(msg)
-        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        if not _fork_warned:                               # once per process: with in_memory=False every sample of the worker gets here
+            _fork_warned = True
+            logging.getLogger("heart_sounds_segmentation_amd").error(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
         raise ForkedAfterGpuInitError(msg)
 
     if hip_owner_pid is not None and hip_owner_pid != pid:

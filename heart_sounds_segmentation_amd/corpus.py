@@ -106,7 +106,10 @@ class CorpusBuilder:
         nfr_np = np.where(L_np <= 0, 1, L_np).astype(np.int64)
         nfr = [int(v) for v in nfr_np]
         total = int(nfr_np.sum())
-        have_labels = total > 0 and all(y is not None for _, y in recs)
+        with_y = sum(1 for _, y in recs if y is not None)
+        if 0 < with_y < len(recs):
+            raise ValueError("CorpusBuilder.build: some recordings carry labels and some do not; pass labels for all or for none")
+        have_labels = total > 0 and with_y == len(recs)
         # groups of about `windows_per_launch` frames (a launch per recording -- 33 frames -- leaves the chip idle)
         groups: List[Tuple[int, int]] = []
         g0, acc = 0, 0
@@ -146,6 +149,10 @@ class CorpusBuilder:
             return FrameItems(feats, labels)
 
         plan = fsst._plan(fsst._device_index(torch.empty(0, device=dev)))
+        if not (getattr(fsst, "stack", False) or getattr(fsst, "abs", False)):
+            # (the raw transform is complex64 (frames, K, n), frequency-major: not the time-major float32 arena this builder fills)
+            raise ValueError("CorpusBuilder.build: the transform must have stack=True or abs=True (time-major float32 features); "
+                             "for the raw complex transform call FSST.frames per group of recordings")
         C = plan.ofps
         shape = (total, frame_len, C)
         if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous()

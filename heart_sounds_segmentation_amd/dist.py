@@ -10,9 +10,10 @@ is testable on CPU with the gloo backend (tests/test_dist.py).
 Where the exchange runs: RCCL moves device memory only, so under the ``nccl`` backend every tensor handed to a
 collective lives on this process's current GPU (host features are staged there first and the result stays there unless
 ``out_device`` says otherwise); under ``gloo`` the tensors stay where they are.  Ragged blocks (the recording-level
-corpus split: a rank's window count depends on its recordings' lengths) are gathered STRAIGHT into the final buffer, one
-broadcast per non-empty rank into that rank's row range -- no padded copy, no concatenation; a rank that holds no
-rows takes part with an empty block.
+corpus split: a rank's window count depends on its recordings' lengths) are gathered STRAIGHT into the final buffer by ONE
+collective over per-rank views of it (RCCL's all_gather takes unequal blocks) -- no padded copy, no concatenation; a rank that
+holds no rows takes part with an empty block.  (gloo, which the CPU tests and the one-GPU dry run use, wants equal blocks: one
+padded all-gather and a compaction.)
 """
 from __future__ import annotations
 
@@ -61,7 +62,7 @@ def all_gather_blocks(local: torch.Tensor, total: int, group: Optional[dist.Proc
                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-gather per-rank feature blocks (block split of ``total`` by ``shard_bounds``) into the
     full batch, in rank order.  Equal blocks: a single ``all_gather_into_tensor`` straight into the
-    result; ragged: one broadcast per rank into its row range of the result."""
+    result; ragged: one all_gather over per-rank views of the result."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [h - l for l, h in (shard_bounds(total, world, r) for r in range(world))]
     if local.shape[0] != counts[rank]:
@@ -102,11 +103,13 @@ def all_gather_ragged(local: Optional[torch.Tensor], group: Optional[dist.Proces
     if src is None:
         raise ValueError("all_gather_ragged: no rank knows the block shape (every rank is empty and none passed `tail`)")
     tail, dtype = tuple(src[4:4 + src[3]]), _DTYPES[src[2]]
-    if local is None:
+    # every rank holds all the metadata: a mismatch is raised on EVERY rank (raised only where it occurs, the others went on
+    # into the collective and hung).  Blocks without rows carry no data and are not held to the shape.
+    bad = [r for r, m in enumerate(meta_l) if m[0] > 0 and (m[1] != 1 or tuple(m[4:4 + m[3]]) != tail or m[2] != src[2])]
+    if bad:
+        raise ValueError(f"all_gather_ragged: the blocks of ranks {bad} do not match the trailing shape {tail} {dtype} of the others")
+    if local is None or local.shape[0] == 0:
         local = torch.empty((0,) + tail, dtype=dtype, device=dev)
-    elif tuple(local.shape[1:]) != tail or local.dtype != dtype:
-        raise ValueError(f"all_gather_ragged: this rank's block {tuple(local.shape)} {local.dtype} does not match "
-                         f"the others' trailing shape {tail} {dtype}")
     full = _gather_counts(local, counts, tail, group, None)
     return full if out_device is None else full.to(out_device)
 
@@ -130,12 +133,20 @@ def _gather_counts(local: torch.Tensor, counts: Sequence[int], tail: Tuple[int, 
         dist.all_gather_into_tensor(out, mine if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() else mine.clone(),
                                     group=group)
         return out
-    works = []
+    if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower():
+        # ONE collective over per-rank views of the result: RCCL's all_gather takes unequal blocks (a grouped set of direct
+        # sends, every block crossing every xGMI link once) -- no padding, no concatenation, and not one ring broadcast per rank
+        views = [out[offs[r]: offs[r + 1]] for r in range(world)]
+        dist.all_gather(views, mine, group=group)
+        return out
+    # gloo (the CPU tests and the one-GPU dry run) insists on equal blocks: ONE all_gather_into_tensor of blocks padded to the
+    # largest count, then the valid rows of every block into place
+    cmax = max(counts)
+    stage = torch.zeros((world, cmax) + tuple(tail), dtype=local.dtype, device=dev)
+    pad = torch.zeros((cmax,) + tuple(tail), dtype=local.dtype, device=dev)
+    pad[: counts[rank]].copy_(mine)
+    dist.all_gather_into_tensor(stage.view((world * cmax,) + tuple(tail)), pad, group=group)
     for r in range(world):
-        if counts[r] == 0:
-            continue
-        works.append(dist.broadcast(out[offs[r]: offs[r + 1]], src=dist.get_global_rank(group, r) if group is not None else r,
-                                    group=group, async_op=True))
-    for wk in works:
-        wk.wait()
+        if counts[r]:
+            out[offs[r]: offs[r + 1]].copy_(stage[r, : counts[r]])
     return out

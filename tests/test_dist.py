@@ -199,3 +199,25 @@ def test_corpus_gather_over_rccl_one_rank(tmp_path):
     tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True, device="cuda:0")
     items = corpus.build_features(_corpus([5200, 1500, 7300, 4100], seed=33), tf)
     assert np.array_equal(np.load(tmp_path / "rccl.npy"), items.features.numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_n_ranks_dry_run_over_gloo(world):
+    """`bench.py --gpus N --dry-run-gloo`: the WHOLE N-rank path of the round-end scaling run -- self-launch through
+    torch.distributed.run on 127.0.0.1, window sharding, the timed C2 steps with barrier + max over ranks, the all-gather of the
+    feature blocks, the C3 recording split with its ragged gather, one JSON line with n_gpus = N -- with every rank on the one
+    leased GPU and the exchange over gloo (RCCL refuses two ranks per device): what is left for an 8-GPU box is RCCL itself."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run-gloo", "--steps", "3", "--warmup", "1",
+           "--settle-steps", "0", "--batch", "32", "--no-cpu-baseline", "--c3-recordings", "24"]
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["unit"] == "windows/s" and d["value"] > 0
+    assert d["config"]["windows_per_gpu"] == 32 and "dry_run" in d["config"]
+    assert "error" not in d.get("allgather", {}) and d["allgather"]["bytes_per_rank"] == 32 * 2000 * 44 * 4
+    c3 = d["c3"]
+    assert "error" not in c3 and c3["n_gpus"] if "n_gpus" in c3 else True
+    assert c3["allgather"]["shape_ok"] is True and "error" not in c3["allgather"]
