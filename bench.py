@@ -63,6 +63,19 @@ def pmc_profile(kernel_substr):
     return None
 
 
+def census_max_rel_err():
+    """Largest per-column error of the canonical kernels against the float64 oracle over the committed 2 M-column census
+    (profiles/r04_split_fold_census.txt, tools/split_fold_census.py): what the 22-bit operands of the fold amount to."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_split_fold_census.txt")) as fh:
+            for ln in fh:
+                if ln.startswith("arithmetic_max_rel_err"):
+                    return float(ln.split()[1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def live_traffic(kernel_substr, batch, timeout_s=150, extra_env=None):
     """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two short child runs of this very script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no tracing, as MI355X_MICROARCH.md prescribes:
@@ -524,6 +537,7 @@ def main():
                        "arithmetic": "float32 throughout; the window fold runs on the f16 matrix pipe with split operands "
                                      "(sample and constant each a pair of halves = 22 bits, fp32 accumulation), every rounding "
                                      "decision float32 cannot make in float64",
+                       "arithmetic_max_rel_err": census_max_rel_err(),
                        "zscore": {1: "same launch (one CU per signal)", 2: "same launch (team kernel)"}.get(fused, "second kernel")},
             "roofline": roof,
         }

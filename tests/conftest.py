@@ -25,3 +25,21 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The parity gate's tally of the session (tests/parity.py): fragile columns met, and how many of them differed."""
+    try:
+        from tests import parity
+    except Exception:
+        return
+    t = parity.TALLY
+    if not t["checks"]:
+        return
+    line = (f"parity tally: {t['checks']} signal checks, {t['columns']} columns, {t['fragile']} within {parity.FRAG_EPS:g} bins of a rounding tie, "
+            f"{t['flipped']} of those differ from the oracle, {t['flipped_strict']} of them farther than {parity.FRAG_STRICT:g} from the tie")
+    print("\n" + line)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_tally.txt"), "w") as fh:
+            fh.write(line + "\n")
