@@ -11,6 +11,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cctype>
+#include <string>
 #include <atomic>
 #include <new>
 #include <thread>
@@ -49,6 +51,68 @@ int fail(int code, const char* fmt, ...)
             return fail(HSSFSST_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// Development / A-B switches, read ONCE per process (first use) from the environment: HSSFSST_DEBUG="key[=value],key,..." with the
+// keys below, or -- the older spelling the tests and tools use -- one variable per key, HSSFSST_<KEY in capitals>[=value].
+// Defaults are the measured best; no switch changes a result (every path gives the same bits, which is what most of them
+// exist to show).  Nothing else in the library reads the environment.
+struct DebugSwitches {
+    bool no_fused = false;        // z-score always as a second kernel
+    bool no_canon = false;        // the canonical band on the general kernels (fsst_mfma128.hpp)
+    bool no_team = false;         // never the team kernel
+    bool team_only = false;       // the team kernel or two launches, never one CU per signal
+    bool team_force_fallback = false;   // every team launch finds itself given up (tests of the gated fallback)
+    bool force_dft = false;       // every window length on the any-length kernel
+    bool force_generic = false;   // every radix length on the generic VALU kernel
+    bool no_mfma256 = false;      // nwin 256 / 512 on the generic kernel
+    bool split_stats = false;     // a separate statistics launch on the two-launch path
+    int team = 0;                 // CUs per team (0: chosen by the library)
+    unsigned team_spin_us = 500;  // bound of a wait inside the team kernel
+    int oneplane_kb = 40;         // generic kernel: one shared LDS plane above this many KB
+    int chunks = 0;               // STACK: k-chunk two-stream pipeline (0 / 1: off)
+    int zgrid = 0, zslices = 0;   // z-score sweep geometry (0: chosen by the library)
+};
+const DebugSwitches& debug_switches()
+{
+    static const DebugSwitches sw = [] {
+        DebugSwitches d;
+        auto set = [&](const std::string& key, const char* val) {
+            const int iv = val ? std::atoi(val) : 0;
+            const bool on = !val || val[0] == '\0' || iv != 0 || val[0] == 'y' || val[0] == 't';
+            if (key == "no_fused") d.no_fused = on; else if (key == "no_canon") d.no_canon = on;
+            else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
+            else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
+            else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
+            else if (key == "split_stats") d.split_stats = on; else if (key == "team") d.team = iv;
+            else if (key == "team_spin_us") d.team_spin_us = static_cast<unsigned>(iv > 0 ? iv : 500);
+            else if (key == "oneplane_kb") d.oneplane_kb = iv; else if (key == "chunks") d.chunks = iv;
+            else if (key == "zgrid") d.zgrid = iv; else if (key == "zslices") d.zslices = iv;
+        };
+        static const char* const keys[] = {"no_fused", "no_canon", "no_team", "team_only", "team_force_fallback", "force_dft", "force_generic",
+                                           "no_mfma256", "split_stats", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
+        for (const char* k : keys) {                       // HSSFSST_<KEY>
+            std::string name = "HSSFSST_";
+            for (const char* c = k; *c; ++c) name += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
+            if (const char* v = std::getenv(name.c_str())) set(k, (name == "HSSFSST_FORCE_GENERIC" && v[0] != '1') ? "0" : v);
+        }
+        if (const char* all = std::getenv("HSSFSST_DEBUG")) {   // HSSFSST_DEBUG="no_fused,team=16"
+            std::string item;
+            for (const char* c = all;; ++c) {
+                if (*c == ',' || *c == '\0') {
+                    if (!item.empty()) {
+                        const size_t eq = item.find('=');
+                        if (eq == std::string::npos) set(item, nullptr);
+                        else set(item.substr(0, eq), item.c_str() + eq + 1);
+                    }
+                    item.clear();
+                    if (*c == '\0') break;
+                } else if (*c != ' ') item += *c;
+            }
+        }
+        return d;
+    }();
+    return sw;
+}
 
 // Makes `device` current for the scope and restores the caller's device on every exit path (a process
 // that drives several GPUs must not find its current HIP device changed by a library call).
@@ -236,7 +300,7 @@ int launch_core(hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblocks, hip
     // wide band: own and displaced values share one plane.  Needed above 160 KiB (nwin 512, > ~150 kept rows) and
     // already worth it above 40 KiB, where LDS is what limits the resident waves (measured, 1024 x 2000, band
     // [25,200] Hz: nwin 256 core 2.25 -> 1.44 ms, nwin 512 18.9 -> 9.4 ms; HSSFSST_ONEPLANE_KB overrides)
-    static const int one_thr = std::getenv("HSSFSST_ONEPLANE_KB") ? std::atoi(std::getenv("HSSFSST_ONEPLANE_KB")) : 40;
+    const int one_thr = debug_switches().oneplane_kb;
     if (lds > static_cast<size_t>(one_thr) * 1024) {
         lds = (static_cast<size_t>(XS) + static_cast<size_t>(2 * pl->K) * (kTile + 1)) * sizeof(float);
         cp.oneplane = 1;
@@ -414,7 +478,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (pl->team16_cus < 1) return 0;
     // team size: the smallest power of two that leaves a CU at most 16 groups of a signal (its 16 waves then have all of them in
     // flight at once and the kernel's progress argument holds); HSSFSST_TEAM=n overrides upwards (A/B)
-    static const int team_env = std::getenv("HSSFSST_TEAM") ? std::atoi(std::getenv("HSSFSST_TEAM")) : 0;
+    const int team_env = debug_switches().team;
     int T = 1;
     while ((WPB / 2) * T < G) T *= 2;                    // (cpc <= WPB is the kernel's progress argument; cpc <= WPB / 2 measured faster:
                                                          //  a signal's groups are handed out within half a round of the CU's waves)
@@ -450,12 +514,12 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale_s = pl->canon_r2s; tp.inv_c = pl->canon_inv_c;
     tp.n = cp.n; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
     tp.team = T; tp.cpc_shift = cpc_shift; tp.slots = slots; tp.seq = pl->team_seq;
-    static const unsigned spin_us = std::getenv("HSSFSST_TEAM_SPIN_US") ? static_cast<unsigned>(std::atoi(std::getenv("HSSFSST_TEAM_SPIN_US"))) : 500u;
+    const unsigned spin_us = debug_switches().team_spin_us;
     tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
     if ((rc = ensure_team_words(pl, st)) != 0) return rc;
     if (++pl->team_launch == 0u) pl->team_launch = 1u;
     tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
-    static const bool force_fallback = std::getenv("HSSFSST_TEAM_FORCE_FALLBACK") != nullptr;   // tests: every team launch finds itself given up
+    const bool force_fallback = debug_switches().team_force_fallback;   // tests: every team launch finds itself given up
     if (force_fallback) {
         HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -475,7 +539,7 @@ using CanonBand = hssfsst::CanonCfg<kCanonKlo, kCanonK>;
 
 bool plan_is_canon(const hssfsst_plan* pl)
 {
-    static const bool off = std::getenv("HSSFSST_NO_CANON") != nullptr;             // A/B and cross-check tests
+    const bool off = debug_switches().no_canon;            // A/B and cross-check tests
     return !off && pl->d_atab16 && pl->nwin == 128 && pl->klo == kCanonKlo && pl->K == kCanonK &&
            (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM);
 }
@@ -592,8 +656,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         // fast as one CU per signal on full batches and 1.3-1.8x faster on small or ragged ones (profiles/r04_batch_sweep.txt): it
         // goes first wherever it applies -- the canonical band, signals of at most 128 groups; one CU per signal (the tile makes a
         // round trip through HBM inside the launch) for the other even bands of <= 24 rows, and as the team kernel's gated fallback
-        static const bool env_no_team = std::getenv("HSSFSST_NO_TEAM") != nullptr;     // A/B and tests
-        static const bool env_team_only = std::getenv("HSSFSST_TEAM_ONLY") != nullptr; // A/B and tests
+        const bool env_no_team = debug_switches().no_team, env_team_only = debug_switches().team_only;      // A/B and tests
         const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
@@ -773,7 +836,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
     if (!window || nwin < 1 || !(fs > 0.0) || mode < 0 || mode > HSSFSST_MODE_STACK_UNNORM)
         return fail(HSSFSST_EINVAL, "plan_create: bad argument (nwin=%d fs=%g mode=%d)", nwin, fs, mode);
     if (nwin > 65535) return fail(HSSFSST_EUNSUPPORTED, "plan_create: window length %d exceeds 65535", nwin);
-    static const bool force_dft = std::getenv("HSSFSST_FORCE_DFT") != nullptr;       // cross-check: every length on the any-length kernel
+    const bool force_dft = debug_switches().force_dft;    // cross-check: every length on the any-length kernel
     const bool radix_len = nwin == 32 || nwin == 64 || nwin == 128 || nwin == 256 || nwin == 512;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -867,9 +930,9 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
             return fail(HSSFSST_EHIP, "plan_create: float64 table upload: %s", hipGetErrorString(e));
         }
     }
-    const char* force = std::getenv("HSSFSST_FORCE_GENERIC");
-    static const bool mfma_long = !(std::getenv("HSSFSST_NO_MFMA256") != nullptr);   // A/B: nwin 256 / 512 on the generic kernel
-    bool use_mfma = !p->dft && (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !(force && force[0] == '1');
+    const bool force_generic = debug_switches().force_generic;
+    const bool mfma_long = !debug_switches().no_mfma256;   // A/B: nwin 256 / 512 on the generic kernel
+    bool use_mfma = !p->dft && (nwin == 128 || ((nwin == 256 || nwin == 512) && mfma_long)) && !force_generic;
     if (p->dft) {
         // A[i][k] of v_mfma_f32_16x16x4_f32 for source block blk, k-step ks: lane l holds row i = l & 15, k = l >> 4.
         // Row i: source k' = 4 blk + (i >> 2), component i & 3 of {V.re, V.im, Vd'.re, Vd'.im}; tap n = 4 ks + k:
@@ -1247,8 +1310,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     const int64_t per = static_cast<int64_t>(ncols) * ofps;
     int64_t nchunks = 1;
     if (p->mode == HSSFSST_MODE_STACK) {
-        const char* ce = std::getenv("HSSFSST_CHUNKS");
-        if (ce && std::atoi(ce) > 0) nchunks = std::atoi(ce);
+        if (debug_switches().chunks > 0) nchunks = debug_switches().chunks;
         if (nchunks > batch) nchunks = batch;
     }
     const int64_t chunk = (batch + nchunks - 1) / nchunks;
@@ -1274,7 +1336,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         hipEvent_t evt = nullptr;
         if (p->timing) { if ((rc = next_event(&evt)) != 0) return rc; HIP_TRY(hipEventRecord(evt, st)); }
         bool did_fuse = false;
-        static const bool no_fused = std::getenv("HSSFSST_NO_FUSED") != nullptr;        // A/B and bit-equality tests
+        const bool no_fused = debug_switches().no_fused;  // A/B and bit-equality tests
         if (p->dft) {
             hssfsst::DftParams dp{};
             dp.x = cx; dp.out = cout; dp.partials = cp.partials; dp.atab = p->d_dtab;
@@ -1344,12 +1406,12 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
                 zs = p->aux;
             }
             float4* cstats = reinterpret_cast<float4*>(p->d_stats) + c0;
-            static const int zgrid_env = std::getenv("HSSFSST_ZGRID") ? std::atoi(std::getenv("HSSFSST_ZGRID")) : 0;
-            static const bool split_stats = std::getenv("HSSFSST_SPLIT_STATS") != nullptr;   // A/B: separate statistics launch
+            const int zgrid_env = debug_switches().zgrid;
+            const bool split_stats = debug_switches().split_stats;   // A/B: separate statistics launch
             int64_t zgrid = zgrid_env > 0 ? zgrid_env : (piped ? 512 : 4096);
             // small batches: several blocks per signal, else one block per signal would leave most CUs idle
             int slices = 1;
-            static const int zslices_env = std::getenv("HSSFSST_ZSLICES") ? std::atoi(std::getenv("HSSFSST_ZSLICES")) : 0;
+            const int zslices_env = debug_switches().zslices;
             if (zslices_env > 0) {
                 slices = zslices_env;
                 zgrid = cb * slices;
