@@ -421,7 +421,8 @@ __device__ __forceinline__ float canon_stats(const f2* own_base, int nvalid, flo
         }
     }
     float w = piece_sums(st_s.x, st_q.x, st_s.y, st_q.y);
-    w *= ((lane_o >> 4) & 1) ? inv * inv : inv;
+    w *= inv;                                            // (the rows of squares: twice -- inv x inv itself leaves float32 for tiny signals)
+    if ((lane_o >> 4) & 1) w *= inv;
     piv_out = piv * f2{inv, inv};
     return w;
 }

@@ -909,6 +909,32 @@ def test_dc_offset_statistics(oracle_mod, band, n, batch):
             parity.check(got[b], ref[b], hd[b], 0, what=f"dc offset band={band} [{b}]")
 
 
+@pytest.mark.parametrize("amp", [1e-17, 1e-12, 1e12, 1e17])
+def test_amplitude_sweep_canonical_band(oracle_mod, amp):
+    """The stated amplitude range (README "Limits"): un-normalised features for samples of 1e-17 .. 1e17 (the tile scale is a power of
+    two taken from sum x^2 in float32), z-scored features for 1e-12 .. 1e17 (the statistics' float32 partials hold the SQUARES of
+    the features -- as the reference's torch.std on its float32 tensors does); all z-score paths agree bit for bit."""
+    X = (synth.pcg_windows(3, 2000, seed=5).astype(np.float64) * amp).astype(np.float32)
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    Xd = torch.from_numpy(X).cuda()
+    raw = tf.unnormalized(Xd).cpu().numpy()
+    rr = oracle_mod.features(X, 1000, KAISER, BAND, "raw", nthreads=3)
+    assert np.isfinite(raw).all()
+    for b in range(3):
+        un = np.concatenate([rr[b].real.T, rr[b].imag.T], axis=1)
+        assert np.abs(raw[b] - un).max() <= 1e-4 * np.abs(un).max(), (amp, b)
+    if amp > 1e-13:
+        outs = {}
+        for zp in ("two_launch", "team"):
+            tf.set_zpath(zp)
+            outs[zp] = tf.batch(Xd).cpu().numpy()
+            tf.check()
+        assert np.isfinite(outs["team"]).all() and np.array_equal(outs["two_launch"], outs["team"])
+        ref, hd = oracle_mod.features(X, 1000, KAISER, BAND, "stack", nthreads=3, return_halfdist=True)
+        for b in range(3):
+            parity.check(outs["team"][b], ref[b], hd[b], 0, what=f"amplitude {amp:g} [{b}]")
+
+
 @pytest.mark.parametrize("n", [2000, 1999, 190, 100, 64])
 def test_offset_signals_stay_in_float32(oracle_mod, n):
     """Recordings that ride on an offset on the canonical band (fsst_canon128.hpp "Offsets": a tile whose mean carries half of
