@@ -13,6 +13,8 @@
  *     with HSSFSST_ENODEVICE otherwise (the CPU restatement lives in oracle/, test-only);
  *   - HIP is touched for the first time inside hssfsst_plan_create(), in the calling process
  *     (fork-safe for DataLoader workers: create the plan after the fork);
+ *   - a plan is SINGLE-STREAM: its execs must be queued on one stream at a time (scratch buffers, the team kernel's arrival
+ *     numbers and mailboxes belong to the plan); use one plan per stream.
  *   - hssfsst_exec() enqueues on `stream` (a hipStream_t, NULL = default stream) and returns
  *     without synchronising when both buffers are device buffers; with a host buffer on either
  *     side it stages through the plan's device scratch and synchronises before returning;
