@@ -683,42 +683,89 @@ __global__ __launch_bounds__(256) void fsst_normalize_kernel(float* out, const f
 // (Chan's pairwise merge == repeated application of update_mean/update_variance, in exact
 // arithmetic).  grid = batch, block = 256.
 // ------------------------------------------------------------------------------------------------
-// Block-wide sums {sum re, sum re^2, sum im, sum im^2} (float64) of one signal's [n][2K] features: every thread of a
-// 1024-thread block gets the totals.  Fixed order (thread-strided, wave butterflies, then the 16 waves in index order):
-// the same numbers whichever kernel calls it.  16-byte loads when the block is float4-addressable; the column of an
-// element is tracked without a division per element.
+// Sums {sum re, sum re^2, sum im, sum im^2} (float64) of one signal's [n][2K] features in a FIXED order that a transform kernel can
+// form on the fly (fsst_core128_kernel<STREAM>): the signal is cut into PIECES of 16 frames (16 x 2K contiguous floats, the
+// last one shorter) -- the 16-frame groups of the transform kernels; within a piece lane l of ONE wave takes the elements
+// 4 (l + 64 i) + {0, 1, 2, 3}, i = 0, 1, ... in that order (the lane-linear float4s of the wide-store epilogue), the 64 lanes are
+// added by the xor butterfly wave_sum; the pieces' sums P_q are added as  wave_sum over l of (P_l + P_{l+64} + ...).
 constexpr int kMomThreads = 1024;
-__device__ inline void chunk_moments(const float* base, int total, int C, int K, int tid, double (*red)[4], double out[4])
-{
-    double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
-    auto acc = [&](float f, int c) {
-        const double v = static_cast<double>(f);
-        if (c < K) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
-    };
-    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
-        const float4* b4 = reinterpret_cast<const float4*>(base);
-        const int tot4 = total >> 2;
-        int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
-        const int dc = static_cast<int>((static_cast<unsigned>(kMomThreads) * 4u) % static_cast<unsigned>(C));
-        for (int i = tid; i < tot4; i += kMomThreads) {
-            const float4 v = b4[i];
-            int c1 = c + 1, c2 = c + 2, c3 = c + 3;
-            if (c1 >= C) c1 -= C;
-            if (c2 >= C) c2 -= C;
-            if (c3 >= C) c3 -= C;
-            acc(v.x, c); acc(v.y, c1); acc(v.z, c2); acc(v.w, c3);
-            c += dc;
-            if (c >= C) c -= C;
-        }
-    } else {
-        for (int i = tid; i < total; i += kMomThreads) acc(base[i], i % C);
+constexpr int kMomPieceFrames = 16;
+struct PlainLoad4 { __device__ float4 operator()(const float4* q) const { return *q; } };
+// Agent-scope loads (sc1): data that blocks on other XCDs wrote with agent-scope stores during this launch
+struct AgentLoad4 {
+    __device__ float4 operator()(const float4* q) const
+    {
+        const unsigned long long* u = reinterpret_cast<const unsigned long long*>(q);
+        const unsigned long long a = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float(static_cast<unsigned>(a)), __uint_as_float(static_cast<unsigned>(a >> 32)),
+                           __uint_as_float(static_cast<unsigned>(b)), __uint_as_float(static_cast<unsigned>(b >> 32)));
     }
-    s0 = wave_sum(s0); q0 = wave_sum(q0); s1 = wave_sum(s1); q1 = wave_sum(q1);
-    if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = q0; red[tid >> 6][2] = s1; red[tid >> 6][3] = q1; }
+};
+// one element into a lane's four accumulators (explicit fma: every site rounds alike)
+__device__ __forceinline__ void mom_acc(double (&a)[4], float f, bool imag)
+{
+    const double v = static_cast<double>(f);
+    if (imag) { a[2] += v; a[3] = fma(v, v, a[3]); } else { a[0] += v; a[1] = fma(v, v, a[1]); }
+}
+// the four elements of float4 number f of a piece (C = 2K floats per frame)
+__device__ __forceinline__ void mom_acc4(double (&a)[4], float4 v, int f, int C, int K)
+{
+    int c = static_cast<int>((4u * static_cast<unsigned>(f)) % static_cast<unsigned>(C));
+    int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+    if (c1 >= C) c1 -= C;
+    if (c2 >= C) c2 -= C;
+    if (c3 >= C) c3 -= C;
+    mom_acc(a, v.x, c >= K); mom_acc(a, v.y, c1 >= K); mom_acc(a, v.z, c2 >= K); mom_acc(a, v.w, c3 >= K);
+}
+// sums of one piece (L floats at pb) by one whole wave; every lane gets them
+__device__ inline void piece_moments(const float* pb, int L, int C, int K, int lane, double (&t)[4])
+{
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool wide = (reinterpret_cast<uintptr_t>(pb) & 15) == 0;
+    for (int f = lane; 4 * f < L; f += 64) {
+        if (wide && 4 * f + 3 < L) mom_acc4(a, *reinterpret_cast<const float4*>(pb + 4 * f), f, C, K);
+        else
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * f + u;
+                if (e < L) mom_acc(a, pb[e], (e % C) >= K);
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = wave_sum(a[e]);
+}
+// the pieces' sums -> the signal's: lane l of one wave adds P_l, P_{l+64}, ... (piece(q, e) = quantity e of piece q), then the butterfly
+template <class Piece>
+__device__ inline void moments_from_pieces(int npieces, int lane, Piece piece, double (&out)[4])
+{
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = lane; q < npieces; q += 64)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += piece(q, e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = wave_sum(a[e]);
+}
+// A 1024-thread block: wave w takes the pieces w, w + 16, ... and adds piece q's sums into its lane q % 64 (lane l's pieces
+// l, l + 64, ... all belong to wave l % 16, in increasing order: the order of moments_from_pieces); sh: [64][4] doubles.
+// Every thread gets the totals.
+__device__ inline void chunk_moments(const float* base, int n, int C, int K, int tid, double (*sh)[4], double out[4])
+{
+    const int lane = tid & 63, w = tid >> 6;
+    const int npieces = (n + kMomPieceFrames - 1) / kMomPieceFrames;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = w; q < npieces; q += kMomThreads / 64) {
+        double t[4];
+        piece_moments(base + static_cast<long long>(q) * kMomPieceFrames * C, min(kMomPieceFrames, n - q * kMomPieceFrames) * C, C, K, lane, t);
+        if (lane == (q & 63))
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += t[e];
+    }
+    if ((lane & 15) == w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sh[lane][e] = a[e];
     __syncthreads();
-    out[0] = out[1] = out[2] = out[3] = 0.0;
-    for (int w2 = 0; w2 < kMomThreads / 64; ++w2)
-        for (int e = 0; e < 4; ++e) out[e] += red[w2][e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = wave_sum(sh[lane][e]);
 }
 
 // Chan merge of one block {sum, sum of squares over nb elements} into the running {count, mean, M2} at st[0..2];
@@ -738,12 +785,12 @@ __device__ inline float2 merge_state(double* st, double s, double q, double nb)
 
 __global__ __launch_bounds__(kMomThreads) void fsst_moments_merge_kernel(const float* feats, double* state, int n, int K)
 {
-    __shared__ double red[kMomThreads / 64][4];
+    __shared__ double sh[64][4];
     const long long b = blockIdx.x;
     const int tid = threadIdx.x;
     const int total = n * 2 * K;                         // < 2^31, checked on the host
     double m[4];
-    chunk_moments(feats + b * static_cast<long long>(total), total, 2 * K, K, tid, red, m);
+    chunk_moments(feats + b * static_cast<long long>(total), n, 2 * K, K, tid, sh, m);
     if (tid < 2) merge_state(state + b * 6 + tid * 3, m[2 * tid], m[2 * tid + 1], static_cast<double>(K) * static_cast<double>(n));
 }
 
@@ -763,30 +810,75 @@ __global__ __launch_bounds__(64) void fsst_stats_from_state_kernel(const double*
 // into its running {count, mean, M2} and then normalises that chunk with the updated moments.  Same arithmetic, same
 // order as fsst_moments_merge_kernel -> fsst_stats_from_state_kernel -> fsst_normalize_kernel: bit-identical results,
 // two launches (and the statistics round trip through HBM) fewer per step.  grid = channels, block = 1024.
-__global__ __launch_bounds__(kMomThreads) void fsst_stream_finish_kernel(float* feats, double* state, int n, int K)
+// The normalisation half of a streaming step's tail: NTH threads of one block, the chunk's [n][2K] floats at base.
+// (Load4: how the chunk is read -- the wide path only: a caller that needs AgentLoad4 has a 16-byte addressable chunk.)
+// Two halves so that a caller can have the chunk's first NPF float4s per thread in flight while it still forms the moments.
+template <int NTH, int NPF, class Load4 = PlainLoad4>
+__device__ inline void stream_normalize_load(const float* base, int n, int K, int tid, float4 (&v)[NPF], Load4 ld4 = Load4())
 {
-    __shared__ double red[kMomThreads / 64][4];
-    __shared__ float4 st_sh;
-    const long long b = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int total = n * 2 * K;
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        const int tot4 = total >> 2;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * NTH;
+            v[k] = ld4(b4 + (i < tot4 ? i : 0));
+        }
+    }
+}
+template <int NTH, int NPF, class Load4 = PlainLoad4>
+__device__ inline void stream_normalize_apply(float* base, int n, int K, int tid, float4 st, float4 (&pre)[NPF], Load4 ld4 = Load4())
+{
     const int C = 2 * K;
     const int total = n * C;                             // < 2^31, checked on the host
-    float* base = feats + b * static_cast<long long>(total);
-    double m[4];
-    chunk_moments(base, total, C, K, tid, red, m);
-    if (tid < 2) {
-        const float2 r = merge_state(state + b * 6 + tid * 3, m[2 * tid], m[2 * tid + 1], static_cast<double>(K) * static_cast<double>(n));
-        if (tid == 0) { st_sh.x = r.x; st_sh.y = r.y; } else { st_sh.z = r.x; st_sh.w = r.y; }
-    }
-    __syncthreads();
-    const float m_re = st_sh.x, i_re = st_sh.y, m_im = st_sh.z, i_im = st_sh.w;
+    const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
     if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
         float4* b4 = reinterpret_cast<float4*>(base);
         const int tot4 = total >> 2;
         int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
-        const int dc = static_cast<int>((static_cast<unsigned>(kMomThreads) * 4u) % static_cast<unsigned>(C));
-        for (int i = tid; i < tot4; i += kMomThreads) {
-            float4 v = b4[i];
+        const int dc = static_cast<int>((static_cast<unsigned>(NTH) * 4u) % static_cast<unsigned>(C));
+        auto one = [&](int i, float4 v) {
+            int c1 = c + 1, c2 = c + 2, c3 = c + 3;
+            if (c1 >= C) c1 -= C;
+            if (c2 >= C) c2 -= C;
+            if (c3 >= C) c3 -= C;
+            v.x = (c < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+            v.y = (c1 < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+            v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+            v.w = (c3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
+            b4[i] = v;
+            c += dc;
+            if (c >= C) c -= C;
+        };
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * NTH;
+            if (i < tot4) one(i, pre[k]);
+        }
+        for (int i = tid + NPF * NTH; i < tot4; i += NTH) one(i, ld4(b4 + i));
+    } else {
+        for (int i = tid; i < total; i += NTH) {
+            const float v = base[i];
+            base[i] = ((i % C) < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
+        }
+    }
+}
+template <int NTH, class Load4 = PlainLoad4>
+__device__ inline void stream_normalize_block(float* base, int n, int K, int tid, float4 st, Load4 ld4 = Load4())
+{
+    float4 none[1];
+    // (no prefetch: every float4 through the loop)
+    const int C = 2 * K;
+    const int total = n * C;
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const int tot4 = total >> 2;
+        float4* b4 = reinterpret_cast<float4*>(base);
+        const float m_re = st.x, i_re = st.y, m_im = st.z, i_im = st.w;
+        int c = static_cast<int>((static_cast<unsigned>(tid) * 4u) % static_cast<unsigned>(C));
+        const int dc = static_cast<int>((static_cast<unsigned>(NTH) * 4u) % static_cast<unsigned>(C));
+        for (int i = tid; i < tot4; i += NTH) {
+            float4 v = ld4(b4 + i);
             int c1 = c + 1, c2 = c + 2, c3 = c + 3;
             if (c1 >= C) c1 -= C;
             if (c2 >= C) c2 -= C;
@@ -800,11 +892,25 @@ __global__ __launch_bounds__(kMomThreads) void fsst_stream_finish_kernel(float* 
             if (c >= C) c -= C;
         }
     } else {
-        for (int i = tid; i < total; i += kMomThreads) {
-            const float v = base[i];
-            base[i] = ((i % C) < K) ? (v - m_re) * i_re : (v - m_im) * i_im;
-        }
+        (void)none;
+        stream_normalize_apply<NTH, 1>(base, n, K, tid, st, none, ld4);       // (takes its scalar path)
     }
+}
+__global__ __launch_bounds__(kMomThreads) void fsst_stream_finish_kernel(float* feats, double* state, int n, int K)
+{
+    __shared__ double sh[64][4];
+    __shared__ float4 st_sh;
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    float* base = feats + b * static_cast<long long>(n) * (2 * K);
+    double m[4];
+    chunk_moments(base, n, 2 * K, K, tid, sh, m);
+    if (tid < 2) {
+        const float2 r = merge_state(state + b * 6 + tid * 3, m[2 * tid], m[2 * tid + 1], static_cast<double>(K) * static_cast<double>(n));
+        if (tid == 0) { st_sh.x = r.x; st_sh.y = r.y; } else { st_sh.z = r.x; st_sh.w = r.y; }
+    }
+    __syncthreads();
+    stream_normalize_block<kMomThreads>(base, n, K, tid, st_sh);
 }
 
 }  // namespace hssfsst

@@ -76,6 +76,14 @@ struct Core128Params {
     long long xstride;    // samples between the starts of consecutive signals (n for a dense batch)
     Core128Regions reg;
     unsigned* status;         // FUSED kernel only: device status word, 0 = ok, else the code of a wait that gave up
+    // STREAM kernel only (one rolling step, hssfsst_stream_step): x = the tape at the oldest sample the step needs, n = hist + chunk
+    const float* xnew;        // the step's new samples [nsig][xnew_stride] (samples hist .. n - 1 of every signal), or null: already in the tape
+    long long xnew_stride;
+    int hist;                 // nwin - 1
+    int bpc;                  // blocks per channel
+    double* state;            // running moments [nsig][6], or null (no normalisation)
+    unsigned* arrive;         // [nsig] blocks of the channel that have delivered (the last one merges and normalises, and clears it)
+    double* pieces;           // [nsig][groups][4] the groups' float64 sums (chunk_moments' pieces, fsst_kernels.hpp)
 };
 
 // Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
@@ -753,7 +761,6 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
         if (mb) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2, ownB, store);
     }
 }
-
 // ------------------------------------------------------------------------------------------------
 // grid = persistent blocks of WPB waves (see "Work distribution" above); each WAVE draws chunks of one signal from
 // the block's LDS counter, stages FPW + 127 samples per FPW frames and walks them in groups of 16 frames,
@@ -779,9 +786,32 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
                                                    // wait is microseconds).  After the first give-up of a block its other
                                                    // waits give up at once (LDS word `dead`), so a broken launch ends fast
 
-template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false>
-__global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
+// STREAM (one step of the rolling transform, BASELINE config 5; FAST epilogue, un-normalised): ONE launch per step instead of
+// copy + transform + merge-and-normalise.  Blocks are bound to channels (bpc blocks per channel, block `part` takes the groups
+// part, part + bpc, ... one group per ticket, staged exactly as the one-group chunks of the plain kernel: same tiles, same bits);
+// a group's samples come from the tape or, from index hist on, straight from the step's new samples, which the group's wave also
+// appends to the tape (nobody reads the tape there during the step); the block that delivers last for its channel (one counter
+// per channel in HBM) runs the arithmetic of fsst_stream_finish_kernel on the channel's chunk.
+#ifdef HSS_STREAM_PROBE      // development (tools/stream_probe.py): 100 MHz ticks from a wave's start to its phase boundaries, kept per wave, written at the end
+constexpr int kStreamProbeWaves = 2048;
+__device__ unsigned long long g_stream_probe[kStreamProbeWaves * 8];      // [wave of the last launch][stamp]
+#define SPROBE(k) do { if constexpr (STREAM) sprobe[k] = wall_clock64() - sprobe_t0; } while (0)
+#else
+#define SPROBE(k) do { } while (0)
+#endif
+// PAIR (nwin 256 / 512, whose transform is two passes over the same 16 frames): TWO waves share one wave region -- wave 2 r does
+// pass 0 of region r's group, wave 2 r + 1 pass 1: fold and spectra at the same time, the odd wave's sources after the even wave's
+// (the order of the additions into the displaced plane is the one-wave kernel's: same bits); the even wave then runs everything
+// that follows the passes.  The pair
+// meets through two phase words in LDS (pair_sync: LDS operations of a wave are executed in order, so a phase word written
+// after a wave's data is seen after it): twice the waves on the same LDS -- 6 instead of 3 per CU for nwin 512 with 90 kept
+// rows -- and half the latency of a lone group (one streaming step).
+constexpr int kPairFloats = 4 + 64;          // [0..1] phase words, [2] the pair's ticket, [4..67] the odd wave's per-lane max |V|^2
+template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false, bool STREAM = false, bool PAIR = false>
+__global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
 {
+    static_assert(!STREAM || (FAST && !FUSED), "the streaming step: wide-store epilogue, no per-signal z-score");
+    static_assert(!PAIR || (RQ == 16 && !FUSED && WPB % 2 == 0), "wave pairs: two passes, whole pairs");
     // (FUSED && !FAST: the general epilogue's STACK mode -- any K, nwin 256 / 512 -- with the linear z-score sweep of
     //  fsst_normalize_kernel as the B ticket; the host sends only STACK execs whose signal blocks are 16-byte aligned)
     constexpr int NWIN = NT * RQ, NPASS = RQ / 8, KST = RQ / 4;
@@ -800,6 +830,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
+#ifdef HSS_STREAM_PROBE
+    const unsigned long long sprobe_t0 = wall_clock64();
+    unsigned long long sprobe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #ifdef HSS_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
@@ -812,18 +846,63 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // FUSED: [64] see "cls" below
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + (FUSED ? 80 : 16));   // [3][64] wide-store offsets (FAST)
     float* part_lds = smem + ATAB + 288;                                     // FUSED: [2][kFusedMaxGroups][kPartFloats]
-    float* wbase = smem + ATAB + CTL + wv * wave_lds_floats(FPW, klo, K, RQ, NT);
+    const int role = PAIR ? (wv & 1) : 0;                                    // PAIR: the pass this wave does
+    float* wbase = smem + ATAB + CTL + (PAIR ? (wv >> 1) : wv) * (wave_lds_floats(FPW, klo, K, RQ, NT) + (PAIR ? kPairFloats : 0));
     float* xs = wbase;
     f2* own_base = reinterpret_cast<f2*>(wbase + XS);
     f2* disp_base = own_base + 16 * OLD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * LDF);
     int* tq = flag + 4;                                                       // rounding-tie bitmap (tie_words(NWIN))
+    int* pw = tq + tie_words(NWIN);                                           // PAIR: phase words, ticket
+    float* pmx = reinterpret_cast<float*>(pw + 4);                            // PAIR: the odd wave's per-lane max
+    if constexpr (PAIR) { if (lane < 4) pw[lane] = 0; }
+    int pphase = 0;
+    auto pair_sync = [&]() {
+        if constexpr (PAIR) {
+            wave_sync();
+            ++pphase;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(pw + role, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_load(pw + (role ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(v) - pphase >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            wave_sync();
+        }
+    };
 
-    // shared MFMA A operand, regrouped so that a lane reads all k-steps of a tap with one LDS instruction:
-    // global [pass * 16 + tap][k-step][lane]  ->  LDS [pass * 16 + tap][lane][k-step]
-    for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) {
-        const int ks = i % KST, l = (i / KST) & 63, pt = i / (KST * 64);
-        atab[i] = p.atab[(pt * KST + ks) * 64 + l];
+    // STREAM: tickets are dealt statically (wave region r takes the block's tickets r, r + regions, ...), so the first group's
+    // samples can be on their way while the operand table is staged
+    constexpr int NREG = PAIR ? WPB / 2 : WPB;
+    constexpr int NPRE = (FPW + NWIN - 1 + 63) / 64;
+    float pre[NPRE];
+    int st_q = PAIR ? (wv >> 1) : wv;
+    auto stream_sample = [&](long long ch, int gi) -> float {     // sample gi of the step's hist + chunk samples of channel ch
+        const float* src = (p.xnew != nullptr && gi >= p.hist) ? p.xnew + ch * p.xnew_stride + (gi - p.hist) : p.x + ch * p.xstride + gi;
+        return *src;
+    };
+    if constexpr (STREAM) {
+        const int ch0 = static_cast<int>(blockIdx.x) / p.bpc, g0 = static_cast<int>(blockIdx.x) - ch0 * p.bpc + st_q * p.bpc;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int gi = g0 * 16 + lane + 64 * k;          // (t0 - NWIN / 2 = 16 g0: the step's frames start at col0 = NWIN / 2)
+            pre[k] = (g0 * 16 < p.ncols && lane + 64 * k < FPW + NWIN - 1 && gi < p.n) ? stream_sample(ch0, gi) : 0.0f;
+        }
+    }
+    // shared MFMA A operand, [pass * NT + tap][lane][k-step]: a lane reads all k-steps of a tap with one LDS instruction
+    // (the host lays the table out like this: a straight 16-byte copy, 64 KiB of it for nwin 512)
+    if constexpr ((ATAB / 4) % (64 * WPB) == 0 && ATAB / 4 / (64 * WPB) <= 16) {
+        constexpr int NA = ATAB / 4 / (64 * WPB);            // all of a thread's loads in flight at once (one memory round trip)
+        float4 t[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) t[k] = reinterpret_cast<const float4*>(p.atab)[threadIdx.x + k * 64 * WPB];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) reinterpret_cast<float4*>(atab)[threadIdx.x + k * 64 * WPB] = t[k];
+    } else {
+        for (int i = threadIdx.x; i < ATAB / 4; i += 64 * WPB)
+            reinterpret_cast<float4*>(atab)[i] = reinterpret_cast<const float4*>(p.atab)[i];
     }
     const int ncols = p.ncols, cend = p.col0 + p.ncols;   // output rows are relative to col0
     for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
@@ -855,6 +934,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         }
     }
     __syncthreads();
+    SPROBE(0);
 
     // chunk bookkeeping (wave-uniform)
     const int nc0 = p.nsig * p.reg.npc[0];               // (the host keeps nsig * chunks per signal below 2^31)
@@ -867,16 +947,26 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     const int nk = (FUSED && p.nsig > static_cast<int>(blockIdx.x)) ? (p.nsig - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : 0;
     const int NC = (ngroups + GPCF - 1) / GPCF;
     const int lead = min(8, NC);
-    const int nwork = FUSED ? 2 * NC * nk : nchunks;
+    const int st_ch = STREAM ? static_cast<int>(blockIdx.x) / p.bpc : 0;              // STREAM: this block's channel and
+    const int st_part = STREAM ? static_cast<int>(blockIdx.x) - st_ch * p.bpc : 0;    // its first group
+    const int nwork = STREAM ? (st_part < ngroups ? (ngroups - st_part + p.bpc - 1) / p.bpc : 0) : FUSED ? 2 * NC * nk : nchunks;
     auto draw = [&]() -> int {                           // next work item of this block, or nwork when none is left
         int q = 0;
         if (lane == 0) q = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         q = __builtin_amdgcn_readfirstlane(q);
-        if constexpr (FUSED) return q < nwork ? q : nwork;
+        if constexpr (FUSED || STREAM) return q < nwork ? q : nwork;
         const long long c = static_cast<long long>(blockIdx.x) + static_cast<long long>(q) * gridDim.x;
         return c < nwork ? static_cast<int>(c) : nwork;
     };
-    int chunk = draw();
+    auto draw_pair = [&]() -> int {                      // PAIR: the even wave draws, the pair takes the ticket together
+        if constexpr (STREAM) { const int q = st_q; st_q += NREG; return q < nwork ? q : nwork; }
+        if constexpr (!PAIR) return draw();
+        if (role == 0) { const int c = draw(); if (lane == 0) pw[2] = c; }
+        pair_sync();
+        return __builtin_amdgcn_readfirstlane(pw[2]);
+    };
+    int chunk = draw_pair();
+    bool first_tile = STREAM;                            // STREAM: the first ticket's samples are in `pre`
     const float* myA = atab + lane * KST;
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));                       // keep it in an SGPR pair (VOP3P takes no literal)
@@ -932,6 +1022,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         b = static_cast<long long>(blockIdx.x) + ksig * gridDim.x;
         grp0 = c * GPCF;
         ngrp = min(GPCF, ngroups - grp0);
+    } else if constexpr (STREAM) {
+        b = st_ch; grp0 = st_part + chunk * p.bpc; ngrp = 1;
     } else {
         const int rg = (chunk < nc0) ? 0 : (chunk < nc1) ? 1 : 2;
         const int local = chunk - ((rg == 0) ? 0 : (rg == 1) ? nc0 : nc1);
@@ -1060,6 +1152,21 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         float e = 0.0f, s1 = 0.0f, cnt = 0.0f;
         int lane_t = lane;                               // (opaque per tile: the tile's lane addresses are not hoisted out of
         asm volatile("" : "+v"(lane_t));                 //  the chunk loop, held across the transform and spilled)
+        if constexpr (STREAM) {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {                 // (the same elements in the same order as the loop below)
+                const int i = lane_t + 64 * k;
+                if (i < FPW + NWIN - 1) {
+                    const int gi = t0 + i - NWIN / 2;
+                    const bool in = (gi >= 0 && gi < n);
+                    const float v = first_tile ? pre[k] : (in ? stream_sample(b, gi) : 0.0f);
+                    xs[i] = v;
+                    e = fmaf(v, v, e); s1 += v; cnt += in ? 1.0f : 0.0f;
+                }
+            }
+            first_tile = false;
+            return tile_energy(e, s1, cnt);
+        }
         for (int i = lane_t; i < FPW + NWIN - 1; i += 64) {
             const int gi = t0 + i - NWIN / 2;
             const bool in = (gi >= 0 && gi < n);
@@ -1075,6 +1182,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
     const TileEnergy te = stage_tile(t0);
     const float R2 = p.r2scale * te.E;
     wave_sync();
+    SPROBE(5);
+    if constexpr (STREAM) {
+        // the group's 16 new samples (hist + 16 grp0 + lane: the last sample of its frame `lane`) go to the tape; the groups of a
+        // channel cover the chunk once
+        if (p.xnew != nullptr && role == 0 && lane < 16 && grp0 * 16 + lane < ncols)
+            const_cast<float*>(xsig)[p.hist + grp0 * 16 + lane] = p.xnew[b * p.xnew_stride + grp0 * 16 + lane];
+    }
     const int gend = min(FPW / 16, ngrp - sub);
     for (int grp = 0; grp < gend; ++grp) {
     const int tg = t0 + grp * 16;
@@ -1088,7 +1202,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         float mx = 0.0f;
         // ---- NPASS passes over the same 16 frames: pass pz handles class pairs 4 pz + g (pair 0 = the two
         //      self-conjugate classes {0, RQ/2}, pair m = {m, RQ - m})
-        static_for<NPASS>([&](auto PZ) {
+        auto one_pass = [&](auto PZ) {
         constexpr int pz = decltype(PZ)::value;
         // keep the per-lane class ids opaque inside the loop: otherwise LICM hoists every
         // "rA + RQ s" of the rare path out of the loop and pins ~30 VGPRs for the whole kernel
@@ -1139,6 +1253,18 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         }
 #else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
+        if constexpr (PAIR && pz == 1) {
+            // the odd wave forms its sources once the even wave is through its pass (it has arrived at the sync behind it): the
+            // displaced plane then receives the additions in the order of the one-wave kernel -- pass 0's, then pass 1's --, the
+            // same bits whoever runs faster; what overlaps is the matrix-pipe fold and the 16 / 32-point spectra
+            for (;;) {
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            wave_sync();
+        }
         static_for<NT / 2>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
             // partner of a[s]: class 0 -> a[(NT-s) mod NT];  else b[NT-1-s].  partner of b[s]: class RQ/2 -> b[NT-1-s]; else a[NT-1-s]
@@ -1158,8 +1284,18 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             if (s1 == NT / 2 && isg0) own_base[j * OLD + NWIN / 2 - RQ * s0] = f2{2.0f * za[NT / 2].x, 0.0f};
         }
 #endif
-        });
-        wave_sync();
+        };
+        if constexpr (PAIR) {
+            if (role == 0) one_pass(std::integral_constant<int, 0>{});
+            else { one_pass(std::integral_constant<int, 1>{}); pmx[lane] = mx; }
+            pair_sync();                                     // both passes are in the planes
+            if (role == 0) mx = fmaxf(mx, pmx[lane]);
+        } else {
+            static_for<NPASS>(one_pass);
+            wave_sync();
+        }
+        SPROBE(6);
+        if (!PAIR || role == 0) {                            // (PAIR: the odd wave waits at the sync that ends the group)
         // one LDS round trip for both per-group flags (dirty displaced plane, queued rounding ties)
         int f_dirty = flag[0];
         const int f_ties = flag[1];
@@ -1263,7 +1399,35 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
                     // streaming stores: the features are not read again by this kernel, and lines left dirty in L2 by
                     // 256 CUs that all write until the last microsecond cost ~10 us of write-back after the kernel
                     if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
+                    else if constexpr (STREAM) {
+                        // read back by the channel's last block, which may sit on another XCD: agent-scope stores (sc1, written
+                        // through) and agent-scope loads there -- no L2 write-back / invalidate fences (measured: they made
+                        // the step 51 us instead of 33)
+                        if (p.state != nullptr) {
+                            unsigned long long* q = reinterpret_cast<unsigned long long*>(dst4 + 64 * i);
+                            __hip_atomic_store(q, static_cast<unsigned long long>(__float_as_uint(o[i].x)) | (static_cast<unsigned long long>(__float_as_uint(o[i].y)) << 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(q + 1, static_cast<unsigned long long>(__float_as_uint(o[i].z)) | (static_cast<unsigned long long>(__float_as_uint(o[i].w)) << 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+                    }
                     else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+                }
+            }
+            if constexpr (STREAM) {
+                // the group IS a piece of the running moments' summation order (fsst_kernels.hpp, chunk_moments): its float64
+                // sums from the image registers -- the elements and the order piece_moments takes from memory
+                if (p.state != nullptr) {
+                    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (lane_o + 64 * i < lim) mom_acc4(a, make_float4(o[i].x, o[i].y, o[i].z, o[i].w), lane_o + 64 * i, C, K);
+                    unsigned long long* pq = reinterpret_cast<unsigned long long*>(p.pieces + (b * ngroups + gidx) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double t = wave_sum(a[e]);
+                        if (lane_o == 0) __hip_atomic_store(pq + e, static_cast<unsigned long long>(__double_as_longlong(t)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             }
@@ -1328,6 +1492,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
             if (lane_o == 0) *flag = 0;
             wave_sync();
         }
+        }
+        pair_sync();                                         // the planes are free for the next group's passes
     }
     }
     if constexpr (FUSED) {
@@ -1353,8 +1519,59 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 
         }
     }
     }
-    chunk = draw();
+    chunk = draw_pair();
     }
+    SPROBE(1);
+    if constexpr (STREAM) {
+        if (p.state != nullptr) {
+            // the channel's last block to get here merges the chunk into the running moments and normalises it
+            // this wave's feature stores (agent scope, written through) are out; the counter below and the loads of the last block
+            // are agent-scope accesses issued after that
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                          // (the operand table in LDS is dead from here on)
+            unsigned* last_sh = reinterpret_cast<unsigned*>(smem);
+            if (threadIdx.x == 0) {
+                const unsigned before = __hip_atomic_fetch_add(p.arrive + st_ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = before + 1u == static_cast<unsigned>(p.bpc);
+                if (last) __hip_atomic_store(p.arrive + st_ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (steps are stream-ordered)
+                last_sh[0] = last ? 1u : 0u;
+            }
+            __syncthreads();
+            SPROBE(2);
+            if (last_sh[0] != 0u) {
+                float4* st_sh = reinterpret_cast<float4*>(smem + 4);
+                float* cbase = p.out + static_cast<long long>(st_ch) * ncols * (2 * K);
+                constexpr int NPF = 6;                       // the chunk's first float4s per thread, in flight during the merge
+                float4 cpre[NPF];
+                stream_normalize_load<64 * WPB, NPF>(cbase, ncols, K, static_cast<int>(threadIdx.x), cpre, AgentLoad4());
+                if (wv == 0) {
+                    const unsigned long long* pq = reinterpret_cast<const unsigned long long*>(p.pieces + static_cast<long long>(st_ch) * ngroups * 4);
+                    double m[4];
+                    moments_from_pieces(ngroups, lane, [&](int q, int e) {
+                        return __longlong_as_double(static_cast<long long>(__hip_atomic_load(pq + q * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                    }, m);
+                    if (lane < 2) {
+                        const float2 r = merge_state(p.state + static_cast<long long>(st_ch) * 6 + lane * 3, m[2 * lane], m[2 * lane + 1],
+                                                     static_cast<double>(K) * static_cast<double>(ncols));
+                        float* sf = reinterpret_cast<float*>(st_sh);
+                        sf[2 * lane] = r.x; sf[2 * lane + 1] = r.y;
+                    }
+                }
+                __syncthreads();
+                SPROBE(3);
+                stream_normalize_apply<64 * WPB, NPF>(cbase, ncols, K, static_cast<int>(threadIdx.x), *st_sh, cpre, AgentLoad4());
+                SPROBE(4);
+            }
+        }
+    }
+#ifdef HSS_STREAM_PROBE
+    if constexpr (STREAM) {
+        sprobe[7] = wall_clock64() - sprobe_t0;
+        const int wid = static_cast<int>(blockIdx.x) * WPB + wv;
+        if (lane == 0 && wid < kStreamProbeWaves)
+            for (int k = 0; k < 8; ++k) g_stream_probe[wid * 8 + k] = sprobe[k];
+    }
+#endif
 #ifdef HSS_CLOCKPROBE
     // development only (STACK_UNNORM, tools/clock_probe.py): HSS_CLOCKPROBE=1 -- shader-clock ticks and 100 MHz ticks one
     // wave in the middle of the grid lived; =2 -- start / end time (100 MHz ticks, low 32 bits) of every wave

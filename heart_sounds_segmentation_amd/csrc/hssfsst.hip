@@ -66,6 +66,8 @@ struct DebugSwitches {
     bool force_generic = false;   // every radix length on the generic VALU kernel
     bool no_mfma256 = false;      // nwin 256 / 512 on the generic kernel
     bool split_stats = false;     // a separate statistics launch on the two-launch path
+    bool no_stream_fuse = false;  // a streaming step as copy + transform + merge-and-normalise launches
+    bool no_pair = false;         // nwin 256 / 512: one wave per wave region (no wave pairs)
     int team = 0;                 // CUs per team (0: chosen by the library)
     unsigned team_spin_us = 500;  // bound of a wait inside the team kernel
     int oneplane_kb = 40;         // generic kernel: one shared LDS plane above this many KB
@@ -83,13 +85,13 @@ const DebugSwitches& debug_switches()
             else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
             else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
             else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
-            else if (key == "split_stats") d.split_stats = on; else if (key == "team") d.team = iv;
+            else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "team") d.team = iv;
             else if (key == "team_spin_us") d.team_spin_us = static_cast<unsigned>(iv > 0 ? iv : 500);
             else if (key == "oneplane_kb") d.oneplane_kb = iv; else if (key == "chunks") d.chunks = iv;
             else if (key == "zgrid") d.zgrid = iv; else if (key == "zslices") d.zslices = iv;
         };
         static const char* const keys[] = {"no_fused", "no_canon", "no_team", "team_only", "team_force_fallback", "force_dft", "force_generic",
-                                           "no_mfma256", "split_stats", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
+                                           "no_mfma256", "split_stats", "no_stream_fuse", "no_pair", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
         for (const char* k : keys) {                       // HSSFSST_<KEY>
             std::string name = "HSSFSST_";
             for (const char* c = k; *c; ++c) name += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -222,7 +224,7 @@ struct hssfsst_plan {
     int dft = 0;                  // 1: this plan runs the any-length kernel
     float r2scale = 0.0f;         // 4 nwin max |(w + i dw') / 2|^2: error-bound scale of the rounding-tie path
     double* d_wtab = nullptr;     // float64 {w, dw' in bin units}[nwin], then {cos, sin}(2 pi m / nwin)[nwin]: rounding-tie path
-    float* d_atab = nullptr;      // nwin == 128 / 256: MFMA A-operand constants [pass][16 taps][k-step][64 lanes]
+    float* d_atab = nullptr;      // nwin == 128 / 256 / 512: MFMA A-operand constants [pass][taps][64 lanes][k-step]
     int rq = 0;                   // first-stage radix of the MFMA kernel, 0 = generic kernel
     float* d_atab16 = nullptr;    // canonical-band kernels (fsst_canon128.hpp): f16 split A operand [16 taps][64 lanes][8 halves]
     float canon_inv_c = 0.0f;     // ... 1 / (power-of-two scale of those constants)
@@ -246,6 +248,9 @@ struct hssfsst_plan {
     int zpath_pref = 0;                                      // HSSFSST_ZPATH_*: preference among the z-score paths
     int last_zpath = 0;                                      // ... which one: 1 = one CU per signal, 2 = team kernel
     int core128_slots = 0;                    // resident blocks of the core kernel on this device (0 = not queried yet)
+    int stream_slots = 0;                     // the same for the streaming-step kernel
+    unsigned* d_stream_arrive = nullptr; int stream_arrive_cap = 0;   // streaming step: blocks delivered per channel
+    double* d_stream_pieces = nullptr; long long stream_pieces_cap = 0;   // and the groups' float64 sums [channels][groups][4]
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
@@ -315,15 +320,22 @@ int launch_core(hssfsst_plan* pl, hssfsst::CoreParams cp, long long nblocks, hip
     return 0;
 }
 
-template <int NT, int RQ, bool FAST, int WPB, int S1C = -1>
+// floats of LDS of a core launch: WPB waves, PAIR: two waves per wave region (fsst_mfma128.hpp "PAIR")
+inline size_t core128_lds_bytes(const hssfsst_plan* pl, int rq, int nt, int wpb, bool pair)
+{
+    const size_t regions = pair ? wpb / 2 : wpb;
+    return (hssfsst::core128_atab_floats(rq, nt) + hssfsst::kCtlFloats + regions *
+            (static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq, nt)) + (pair ? hssfsst::kPairFloats : 0))) * sizeof(float);
+}
+
+template <int NT, int RQ, bool FAST, int WPB, int S1C = -1, bool PAIR = false>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
-    size_t lds = (hssfsst::core128_atab_floats(RQ, NT) + hssfsst::kCtlFloats + static_cast<size_t>(WPB) *
-                        hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, RQ, NT)) * sizeof(float);
+    size_t lds = core128_lds_bytes(pl, RQ, NT, WPB, PAIR);
 #ifdef HSS_LDS_PAD                                       // development: one block per CU whatever its size
     if (lds < 100 * 1024) lds = 100 * 1024;
 #endif
-    auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, FAST, WPB, S1C>;
+    auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, FAST, WPB, S1C, false, false, PAIR>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->core128_slots == 0) {                        // persistent grid = what is resident at once
@@ -336,10 +348,58 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     }
     int64_t blocks = nchunks;                            // small launches: one chunk per block, spread over the CUs
     if (blocks > pl->core128_slots) blocks = pl->core128_slots;
-    name_kernel(pl, WPB, blocks, "fsst_core128_kernel<%d, %d, %d, %s, %d, %d, false>", NT, RQ, kFpw128, FAST ? "true" : "false", WPB, S1C);
+    name_kernel(pl, WPB, blocks, "fsst_core128_kernel<%d, %d, %d, %s, %d, %d, false%s>", NT, RQ, kFpw128, FAST ? "true" : "false", WPB, S1C, PAIR ? ", pairs" : "");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// One rolling step in ONE launch (fsst_core128_kernel<.., STREAM>, fsst_mfma128.hpp): the chunk's groups, one per ticket, blocks
+// bound to channels; tape append, transform, running-moments merge and normalisation.  Returns 1 when it launched, 0 when the
+// step should take the three-launch route (a shape whose plain transform would not be this kernel's one-group chunks).
+template <int NT, int RQ, int WPB, bool PAIR>
+int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const float* x_new_dev, long long x_stride, int channels, int chunk,
+                  float* out, double* state, hipStream_t st)
+{
+    const int ngroups = (chunk + 15) / 16;
+    const hssfsst::Core128Regions reg = hssfsst::core128_regions(ngroups, channels);
+    if (!(reg.npc[0] == 0 && reg.npc[1] == 0 && reg.gpc[2] == 1)) return 0;      // (the plain kernel's chunks are not single groups)
+    const size_t lds = core128_lds_bytes(pl, RQ, NT, WPB, PAIR);
+    if (lds > kMaxLdsBytes) return 0;
+    auto kern = hssfsst::fsst_core128_kernel<NT, RQ, kFpw128, true, WPB, -1, false, true, PAIR>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->stream_slots == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->stream_slots = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
+    }
+    if (state && pl->stream_arrive_cap < channels) {
+        if (pl->d_stream_arrive) { HIP_TRY(hipFree(pl->d_stream_arrive)); pl->d_stream_arrive = nullptr; pl->stream_arrive_cap = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_arrive), static_cast<size_t>(channels) * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(pl->d_stream_arrive, 0, static_cast<size_t>(channels) * sizeof(unsigned), st));
+        pl->stream_arrive_cap = channels;
+    }
+    if (state && pl->stream_pieces_cap < static_cast<long long>(channels) * ngroups) {
+        if (pl->d_stream_pieces) { HIP_TRY(hipFree(pl->d_stream_pieces)); pl->d_stream_pieces = nullptr; pl->stream_pieces_cap = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_pieces), static_cast<size_t>(channels) * ngroups * 4 * sizeof(double)));
+        pl->stream_pieces_cap = static_cast<long long>(channels) * ngroups;
+    }
+    int bpc = pl->stream_slots / channels;                // blocks per channel: spread a small step over the chip
+    if (bpc > ngroups) bpc = ngroups;
+    if (bpc < 1) bpc = 1;
+    hssfsst::Core128Params cp{};
+    cp.x = tape_at; cp.xstride = tape_len; cp.out = out; cp.partials = nullptr; cp.atab = pl->d_atab;
+    cp.wtab = pl->d_wtab; cp.twtab = pl->d_wtab + 2 * pl->nwin; cp.r2scale = pl->r2scale;
+    cp.n = pl->nwin - 1 + chunk; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = channels;
+    cp.col0 = pl->nwin / 2; cp.ncols = chunk; cp.reg = reg;
+    cp.xnew = x_new_dev; cp.xnew_stride = x_stride; cp.hist = pl->nwin - 1; cp.bpc = bpc; cp.state = state; cp.arrive = pl->d_stream_arrive; cp.pieces = pl->d_stream_pieces;
+    const long long grid = static_cast<long long>(channels) * bpc;
+    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "");
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
+    HIP_TRY(hipGetLastError());
+    return 1;
 }
 
 int grow(void** ptr, size_t* cap, size_t need, size_t elem)
@@ -737,6 +797,8 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 8, false, 4>(pl, cp, nchunks, st);
 #ifndef HSS_DEV_ONLY128
     } else if (nt == 16 && rq == 16) {                                               // nwin = 256
+        // (wave pairs -- fsst_mfma128.hpp "PAIR" -- lose here: 16 waves at 128 registers spill, core 0.770 vs 0.587 ms per 1024
+        //  windows; 12 waves at 170 registers: 0.739 ms)
         // (8 waves per block at most: two per SIMD, up to 256 VGPRs, no scratch)
         if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, true, 8>(pl, cp, nchunks, st);
         if (!fast && canon && fixed + 8 * per_wave <= room) return launch_core128_wpb<16, 16, false, 8, 3>(pl, cp, nchunks, st);
@@ -744,6 +806,12 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         if (!fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 16, false, 4>(pl, cp, nchunks, st);
         if (fast && fixed + 4 * per_wave <= room) return launch_core128_wpb<16, 16, true, 4>(pl, cp, nchunks, st);
     } else {                                                                         // nt == 32, rq == 16: nwin = 512
+        if (!debug_switches().no_pair) {                                             // (two waves per SIMD at most: 32-point spectra in registers)
+            if (fast && core128_lds_bytes(pl, 16, 32, 8, true) <= room) return launch_core128_wpb<32, 16, true, 8, -1, true>(pl, cp, nchunks, st);
+            if (!fast && core128_lds_bytes(pl, 16, 32, 8, true) <= room) return launch_core128_wpb<32, 16, false, 8, -1, true>(pl, cp, nchunks, st);
+            if (!fast && core128_lds_bytes(pl, 16, 32, 6, true) <= room) return launch_core128_wpb<32, 16, false, 6, -1, true>(pl, cp, nchunks, st);
+            if (!fast && core128_lds_bytes(pl, 16, 32, 4, true) <= room) return launch_core128_wpb<32, 16, false, 4, -1, true>(pl, cp, nchunks, st);
+        }
         if (fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<32, 16, true, 8>(pl, cp, nchunks, st);
         if (!fast && fixed + 8 * per_wave <= room) return launch_core128_wpb<32, 16, false, 8>(pl, cp, nchunks, st);
         if (!fast && fixed + 6 * per_wave <= room) return launch_core128_wpb<32, 16, false, 6>(pl, cp, nchunks, st);
@@ -779,6 +847,17 @@ int hssfsst_dev_t16_probe(unsigned long long* out16)
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hssfsst::g_t16_probe), sizeof(z)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_probe), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+#ifdef HSS_STREAM_PROBE
+int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nwaves][8] of the last launch; cleared
+{
+    if (nwaves > hssfsst::kStreamProbeWaves) nwaves = hssfsst::kStreamProbeWaves;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_stream_probe), sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return -1;
+    std::vector<unsigned long long> z(static_cast<size_t>(hssfsst::kStreamProbeWaves) * 8, 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_stream_probe), z.data(), z.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
     return 0;
 }
 #endif
@@ -993,7 +1072,7 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                         const double sg = (r & 1) ? -0.5 : 0.5;
                         const double wv = window[n + nt * q], dv = dwb[n + nt * q];
                         const double re = sg * (wv * c - dv * sn), im = sg * (wv * sn + dv * c);
-                        at[(((pz * nt + n) * kst) + ks) * 64 + l] = static_cast<float>((sub & 1) ? im : re);
+                        at[((pz * nt + n) * 64 + l) * kst + ks] = static_cast<float>((sub & 1) ? im : re);      // [pass][tap][lane][k-step]: the kernel's LDS layout
                     }
         static_assert(sizeof(int) == sizeof(float), "offset table shares the float buffer");
         {
@@ -1105,6 +1184,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_dtab) (void)hipFree(p->d_dtab);
     if (p->d_atab) (void)hipFree(p->d_atab);
     if (p->d_atab16) (void)hipFree(p->d_atab16);
+    if (p->d_stream_arrive) (void)hipFree(p->d_stream_arrive);
+    if (p->d_stream_pieces) (void)hipFree(p->d_stream_pieces);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
@@ -1614,16 +1695,42 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
     if (p->K == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEVICE_SCOPE(p->device);
-    HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
-                             static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels),
-                             x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    // frame j of the chunk = samples [pos - hist + j, pos - hist + j + nwin): column nwin/2 + j of the zero-padded
-    // transform of the last hist + chunk samples
-    int rc = hssfsst_exec_frames(p, tape + (pos - hist), channels, static_cast<int>(hist + chunk), tape_len, p->nwin / 2, chunk, 1, out, 1, stream);
-    if (rc != 0) return rc;
-    if (state) {
-        hipLaunchKernelGGL(hssfsst::fsst_stream_finish_kernel, dim3(static_cast<unsigned>(channels)), dim3(hssfsst::kMomThreads), 0, st, out, state, chunk, p->K);
-        HIP_TRY(hipGetLastError());
+    // one launch for the whole step where the transform is the wide-store MFMA kernel in one-group chunks (nwin 256 / 512, an even
+    // band of <= 24 rows: BASELINE config 5); host samples are copied into the tape first and the kernel reads them there
+    const bool one_launch = p->d_atab != nullptr && p->rq == 16 && (p->K & 1) == 0 && p->K <= 24 && !debug_switches().no_stream_fuse &&
+                            (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                            static_cast<long long>(channels) * ((chunk + 15) / 16) < 0x7fffffffLL;
+    int launched = 0;
+    if (one_launch) {
+        if (!x_on_device)
+            HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
+                                     static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyHostToDevice, st));
+        const float* xd = x_on_device ? x_new : nullptr;
+        // (wave pairs: the step's latency is one group's; regions of a block = 2)
+        if (debug_switches().no_pair)
+            launched = (p->nt == 32) ? launch_stream<32, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st)
+                                     : launch_stream<16, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st);
+        else
+            launched = (p->nt == 32) ? launch_stream<32, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st)
+                                     : launch_stream<16, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st);
+        if (launched < 0) return launched;
+        if (launched == 0 && x_on_device)
+            HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
+                                     static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
+                                 static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels),
+                                 x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    if (launched == 0) {
+        // frame j of the chunk = samples [pos - hist + j, pos - hist + j + nwin): column nwin/2 + j of the zero-padded
+        // transform of the last hist + chunk samples
+        int rc = hssfsst_exec_frames(p, tape + (pos - hist), channels, static_cast<int>(hist + chunk), tape_len, p->nwin / 2, chunk, 1, out, 1, stream);
+        if (rc != 0) return rc;
+        if (state) {
+            hipLaunchKernelGGL(hssfsst::fsst_stream_finish_kernel, dim3(static_cast<unsigned>(channels)), dim3(hssfsst::kMomThreads), 0, st, out, state, chunk, p->K);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (out_host) {
         HIP_TRY(hipMemcpyAsync(out_host, out, static_cast<size_t>(channels) * chunk * 2 * p->K * sizeof(float), hipMemcpyDeviceToHost, st));
