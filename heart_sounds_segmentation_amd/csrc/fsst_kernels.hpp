@@ -827,8 +827,9 @@ __device__ inline void stream_normalize_load(const float* base, int n, int K, in
         }
     }
 }
+// (mirror: a second destination for the normalised chunk -- the caller's pinned host buffer -- or null)
 template <int NTH, int NPF, class Load4 = PlainLoad4>
-__device__ inline void stream_normalize_apply(float* base, int n, int K, int tid, float4 st, float4 (&pre)[NPF], Load4 ld4 = Load4())
+__device__ inline void stream_normalize_apply(float* base, int n, int K, int tid, float4 st, float4 (&pre)[NPF], Load4 ld4 = Load4(), float* mirror = nullptr)
 {
     const int C = 2 * K;
     const int total = n * C;                             // < 2^31, checked on the host
@@ -848,6 +849,7 @@ __device__ inline void stream_normalize_apply(float* base, int n, int K, int tid
             v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
             v.w = (c3 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
             b4[i] = v;
+            if (mirror) reinterpret_cast<float4*>(mirror)[i] = v;
             c += dc;
             if (c >= C) c -= C;
         };

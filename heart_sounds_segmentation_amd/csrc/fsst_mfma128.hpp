@@ -84,6 +84,10 @@ struct Core128Params {
     double* state;            // running moments [nsig][6], or null (no normalisation)
     unsigned* arrive;         // [nsig] blocks of the channel that have delivered (the last one merges and normalises, and clears it)
     double* pieces;           // [nsig][groups][4] the groups' float64 sums (chunk_moments' pieces, fsst_kernels.hpp)
+    float* mirror;            // the caller's pinned host buffer for the step's features (device view), or null
+    unsigned* flags;          // [nsig][groups] wait mode: the step (epoch) whose sums a group's entry of `pieces` holds
+    unsigned epoch;           // this step
+    int wait_mode;            // every wave region has ONE group and the grid is resident at once: see the kernel, "wait mode"
 };
 
 // Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
@@ -792,6 +796,12 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
 // a group's samples come from the tape or, from index hist on, straight from the step's new samples, which the group's wave also
 // appends to the tape (nobody reads the tape there during the step); the block that delivers last for its channel (one counter
 // per channel in HBM) runs the arithmetic of fsst_stream_finish_kernel on the channel's chunk.
+// "wait mode" of the streaming step (see the kernel): built, bit-identical, 2 us less host-visible latency and 4 % fewer steps per
+// second when steps are queued back to back (every block stays to the end of its launch, so consecutive launches no longer
+// overlap head to tail): compiled out by default.
+#ifndef HSS_STREAM_WAIT
+#define HSS_STREAM_WAIT 0
+#endif
 #ifdef HSS_STREAM_PROBE      // development (tools/stream_probe.py): 100 MHz ticks from a wave's start to its phase boundaries, kept per wave, written at the end
 constexpr int kStreamProbeWaves = 2048;
 __device__ unsigned long long g_stream_probe[kStreamProbeWaves * 8];      // [wave of the last launch][stamp]
@@ -806,6 +816,7 @@ __device__ unsigned long long g_stream_probe[kStreamProbeWaves * 8];      // [wa
 // meets through two phase words in LDS (pair_sync: LDS operations of a wave are executed in order, so a phase word written
 // after a wave's data is seen after it): twice the waves on the same LDS -- 6 instead of 3 per CU for nwin 512 with 90 kept
 // rows -- and half the latency of a lone group (one streaming step).
+constexpr unsigned kPairSpinLimit = 1u << 24;       // looks at the partner's phase word before a pair's wait ends on its own (~1 s)
 constexpr int kPairFloats = 4 + 64;          // [0..1] phase words, [2] the pair's ticket, [4..67] the odd wave's per-lane max |V|^2
 template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false, bool STREAM = false, bool PAIR = false>
 __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
@@ -863,7 +874,9 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
             ++pphase;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(pw + role, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (;;) {
+            // (bounded like every wait of this library: the partner is a wave of the same workgroup and cannot stay away, but a
+            //  kernel that could spin for ever is a kernel that can hang a GPU)
+            for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
                 int v = 0;
                 if (lane == 0) v = __hip_atomic_load(pw + (role ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__builtin_amdgcn_readfirstlane(v) - pphase >= 0) break;
@@ -883,8 +896,13 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
         const float* src = (p.xnew != nullptr && gi >= p.hist) ? p.xnew + ch * p.xnew_stride + (gi - p.hist) : p.x + ch * p.xstride + gi;
         return *src;
     };
+    double* s6 = reinterpret_cast<double*>(smem + ATAB + 2);      // STREAM, wait mode: the channel's running moments as they are
+                                                                  // before this step (control words 2..13)
     if constexpr (STREAM) {
         const int ch0 = static_cast<int>(blockIdx.x) / p.bpc, g0 = static_cast<int>(blockIdx.x) - ch0 * p.bpc + st_q * p.bpc;
+        // (read before this block publishes anything -- the prologue's barrier is behind it --: the one wave that writes them back
+        //  does so only after it has seen every group's flag)
+        if ((HSS_STREAM_WAIT && p.wait_mode) && threadIdx.x < 6) s6[threadIdx.x] = p.state[static_cast<long long>(ch0) * 6 + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int gi = g0 * 16 + lane + 64 * k;          // (t0 - NWIN / 2 = 16 g0: the step's frames start at col0 = NWIN / 2)
@@ -1257,7 +1275,7 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
             // the odd wave forms its sources once the even wave is through its pass (it has arrived at the sync behind it): the
             // displaced plane then receives the additions in the order of the one-wave kernel -- pass 0's, then pass 1's --, the
             // same bits whoever runs faster; what overlaps is the matrix-pipe fold and the 16 / 32-point spectra
-            for (;;) {
+            for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
                 int v = 0;
                 if (lane == 0) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) break;
@@ -1400,16 +1418,22 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
                     // 256 CUs that all write until the last microsecond cost ~10 us of write-back after the kernel
                     if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
                     else if constexpr (STREAM) {
-                        // read back by the channel's last block, which may sit on another XCD: agent-scope stores (sc1, written
-                        // through) and agent-scope loads there -- no L2 write-back / invalidate fences (measured: they made
-                        // the step 51 us instead of 33)
-                        if (p.state != nullptr) {
+                        if (p.state != nullptr && (HSS_STREAM_WAIT && p.wait_mode)) {
+                            // (wait mode: stored once, normalised, below)
+                        } else if (p.state != nullptr) {
+                            // read back by the channel's last block, which may sit on another XCD: agent-scope stores (sc1, written
+                            // through) and agent-scope loads there -- no L2 write-back / invalidate fences (measured: they made
+                            // the step 51 us instead of 33)
                             unsigned long long* q = reinterpret_cast<unsigned long long*>(dst4 + 64 * i);
                             __hip_atomic_store(q, static_cast<unsigned long long>(__float_as_uint(o[i].x)) | (static_cast<unsigned long long>(__float_as_uint(o[i].y)) << 32),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(q + 1, static_cast<unsigned long long>(__float_as_uint(o[i].z)) | (static_cast<unsigned long long>(__float_as_uint(o[i].w)) << 32),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+                        } else {
+                            __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
+                            if (p.mirror != nullptr)         // (no normalisation: the features are final, the host copy is written here)
+                                __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(p.mirror + (b * static_cast<long long>(ncols) + tr) * C) + lane_o + 64 * i);
+                        }
                     }
                     else __builtin_nontemporal_store(o[i], reinterpret_cast<f4*>(dst4 + 64 * i));
                 }
@@ -1427,6 +1451,56 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
                     for (int e = 0; e < 4; ++e) {
                         const double t = wave_sum(a[e]);
                         if (lane_o == 0) __hip_atomic_store(pq + e, static_cast<unsigned long long>(__double_as_longlong(t)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if ((HSS_STREAM_WAIT && p.wait_mode)) {
+                        // ---- wait mode: the channel's groups are all in flight at once (one per wave region, the grid resident), so
+                        // this wave keeps its image in registers, tells the others that its sums are there (a flag word per group,
+                        // set to this step's number behind the sums), waits for theirs, forms the channel's moments in the order of
+                        // chunk_moments, merges them into its copy of the running moments (merge_state: every wave the same
+                        // numbers; the wave of group 0 writes them back) and stores its features ONCE, normalised.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        unsigned* fl = p.flags + b * ngroups;
+                        if (lane_o == 0) __hip_atomic_store(fl + gidx, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bool there = false;
+                        for (unsigned spins = 0; spins < (1u << 20); ++spins) {      // (~0.1 us per look: gives up after ~0.1 s)
+                            const unsigned f = (lane_o < ngroups) ? __hip_atomic_load(fl + lane_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.epoch;
+                            if (__builtin_amdgcn_ballot_w64(f != p.epoch) == 0ull) { there = true; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (!there) {
+                            if (lane_o == 0) __hip_atomic_store((gu32*)(p.status), 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        } else {
+                            const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(p.pieces + b * ngroups * 4);
+                            double m[4];
+                            moments_from_pieces(ngroups, lane_o, [&](int q, int e) {
+                                return __longlong_as_double(static_cast<long long>(__hip_atomic_load(pa + q * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                            }, m);
+                            const bool im_blk = (lane_o & 1) != 0;       // lane 0: the real block's moments, lane 1: the imaginary block's
+                            double loc[3] = {im_blk ? s6[3] : s6[0], im_blk ? s6[4] : s6[1], im_blk ? s6[5] : s6[2]};
+                            const float2 r = merge_state(loc, im_blk ? m[2] : m[0], im_blk ? m[3] : m[1], static_cast<double>(K) * static_cast<double>(ncols));
+                            if (gidx == 0 && lane_o < 2) {
+                                double* sp = p.state + b * 6 + lane_o * 3;
+                                sp[0] = loc[0]; sp[1] = loc[1]; sp[2] = loc[2];
+                            }
+                            const float m_re = __shfl(r.x, 0, 64), i_re = __shfl(r.y, 0, 64), m_im = __shfl(r.x, 1, 64), i_im = __shfl(r.y, 1, 64);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                if (lane_o + 64 * i < lim) {
+                                    const int c = static_cast<int>((4u * static_cast<unsigned>(lane_o + 64 * i)) % static_cast<unsigned>(C));
+                                    int c2 = c + 2;
+                                    if (c2 >= C) c2 -= C;
+                                    // ((v - mean) * (1 / std), the arithmetic of stream_normalize_apply; K is even: a pair shares its block)
+                                    f4 v = o[i];
+                                    v.x = (c < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
+                                    v.y = (c < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
+                                    v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
+                                    v.w = (c2 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
+                                    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst4 + 64 * i));
+                                    if (p.mirror != nullptr)
+                                        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p.mirror + (b * static_cast<long long>(ncols) + tr) * C) + lane_o + 64 * i);
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -1523,7 +1597,7 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
     }
     SPROBE(1);
     if constexpr (STREAM) {
-        if (p.state != nullptr) {
+        if (p.state != nullptr && !(HSS_STREAM_WAIT && p.wait_mode)) {
             // the channel's last block to get here merges the chunk into the running moments and normalises it
             // this wave's feature stores (agent scope, written through) are out; the counter below and the loads of the last block
             // are agent-scope accesses issued after that
@@ -1559,7 +1633,8 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
                 }
                 __syncthreads();
                 SPROBE(3);
-                stream_normalize_apply<64 * WPB, NPF>(cbase, ncols, K, static_cast<int>(threadIdx.x), *st_sh, cpre, AgentLoad4());
+                stream_normalize_apply<64 * WPB, NPF>(cbase, ncols, K, static_cast<int>(threadIdx.x), *st_sh, cpre, AgentLoad4(),
+                                                      p.mirror ? p.mirror + static_cast<long long>(st_ch) * ncols * (2 * K) : nullptr);
                 SPROBE(4);
             }
         }

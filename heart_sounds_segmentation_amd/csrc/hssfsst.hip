@@ -68,6 +68,7 @@ struct DebugSwitches {
     bool split_stats = false;     // a separate statistics launch on the two-launch path
     bool no_stream_fuse = false;  // a streaming step as copy + transform + merge-and-normalise launches
     bool no_pair = false;         // nwin 256 / 512: one wave per wave region (no wave pairs)
+    bool no_stream_wait = false;  // streaming step: the channel's last block normalises (no waiting between blocks)
     int team = 0;                 // CUs per team (0: chosen by the library)
     unsigned team_spin_us = 500;  // bound of a wait inside the team kernel
     int oneplane_kb = 40;         // generic kernel: one shared LDS plane above this many KB
@@ -85,13 +86,13 @@ const DebugSwitches& debug_switches()
             else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
             else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
             else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
-            else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "team") d.team = iv;
+            else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "no_stream_wait") d.no_stream_wait = on; else if (key == "team") d.team = iv;
             else if (key == "team_spin_us") d.team_spin_us = static_cast<unsigned>(iv > 0 ? iv : 500);
             else if (key == "oneplane_kb") d.oneplane_kb = iv; else if (key == "chunks") d.chunks = iv;
             else if (key == "zgrid") d.zgrid = iv; else if (key == "zslices") d.zslices = iv;
         };
         static const char* const keys[] = {"no_fused", "no_canon", "no_team", "team_only", "team_force_fallback", "force_dft", "force_generic",
-                                           "no_mfma256", "split_stats", "no_stream_fuse", "no_pair", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
+                                           "no_mfma256", "split_stats", "no_stream_fuse", "no_pair", "no_stream_wait", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
         for (const char* k : keys) {                       // HSSFSST_<KEY>
             std::string name = "HSSFSST_";
             for (const char* c = k; *c; ++c) name += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -251,6 +252,9 @@ struct hssfsst_plan {
     int stream_slots = 0;                     // the same for the streaming-step kernel
     unsigned* d_stream_arrive = nullptr; int stream_arrive_cap = 0;   // streaming step: blocks delivered per channel
     double* d_stream_pieces = nullptr; long long stream_pieces_cap = 0;   // and the groups' float64 sums [channels][groups][4]
+    unsigned* d_stream_flags = nullptr; unsigned stream_epoch = 0;        // ... with the step they belong to (wait mode)
+    const float* pin_host[2] = {nullptr, nullptr}; const float* pin_dev[2] = {nullptr, nullptr}; int pin_next = 0;   // pinned host chunks seen (device view)
+    float* pin_out_host[2] = {nullptr, nullptr}; float* pin_out_dev[2] = {nullptr, nullptr}; int pin_out_next = 0;   // and pinned host destinations
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
@@ -357,9 +361,11 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
 // One rolling step in ONE launch (fsst_core128_kernel<.., STREAM>, fsst_mfma128.hpp): the chunk's groups, one per ticket, blocks
 // bound to channels; tape append, transform, running-moments merge and normalisation.  Returns 1 when it launched, 0 when the
 // step should take the three-launch route (a shape whose plain transform would not be this kernel's one-group chunks).
+int ensure_status(hssfsst_plan* pl);
+
 template <int NT, int RQ, int WPB, bool PAIR>
 int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const float* x_new_dev, long long x_stride, int channels, int chunk,
-                  float* out, double* state, hipStream_t st)
+                  float* out, double* state, float* mirror, hipStream_t st)
 {
     const int ngroups = (chunk + 15) / 16;
     const hssfsst::Core128Regions reg = hssfsst::core128_regions(ngroups, channels);
@@ -383,9 +389,13 @@ int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const fl
     }
     if (state && pl->stream_pieces_cap < static_cast<long long>(channels) * ngroups) {
         if (pl->d_stream_pieces) { HIP_TRY(hipFree(pl->d_stream_pieces)); pl->d_stream_pieces = nullptr; pl->stream_pieces_cap = 0; }
+        if (pl->d_stream_flags) { HIP_TRY(hipFree(pl->d_stream_flags)); pl->d_stream_flags = nullptr; }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_pieces), static_cast<size_t>(channels) * ngroups * 4 * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_flags), static_cast<size_t>(channels) * ngroups * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(pl->d_stream_flags, 0, static_cast<size_t>(channels) * ngroups * sizeof(unsigned), st));
         pl->stream_pieces_cap = static_cast<long long>(channels) * ngroups;
     }
+    if (int rcs = ensure_status(pl)) return rcs;
     int bpc = pl->stream_slots / channels;                // blocks per channel: spread a small step over the chip
     if (bpc > ngroups) bpc = ngroups;
     if (bpc < 1) bpc = 1;
@@ -394,9 +404,15 @@ int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const fl
     cp.wtab = pl->d_wtab; cp.twtab = pl->d_wtab + 2 * pl->nwin; cp.r2scale = pl->r2scale;
     cp.n = pl->nwin - 1 + chunk; cp.klo = pl->klo; cp.K = pl->K; cp.mode = pl->mode; cp.nsig = channels;
     cp.col0 = pl->nwin / 2; cp.ncols = chunk; cp.reg = reg;
-    cp.xnew = x_new_dev; cp.xnew_stride = x_stride; cp.hist = pl->nwin - 1; cp.bpc = bpc; cp.state = state; cp.arrive = pl->d_stream_arrive; cp.pieces = pl->d_stream_pieces;
+    cp.xnew = x_new_dev; cp.xnew_stride = x_stride; cp.hist = pl->nwin - 1; cp.bpc = bpc; cp.state = state; cp.arrive = pl->d_stream_arrive; cp.pieces = pl->d_stream_pieces; cp.mirror = mirror;
     const long long grid = static_cast<long long>(channels) * bpc;
-    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "");
+    // wait mode (fsst_mfma128.hpp): every group of a channel in flight at once and the whole grid resident -- the features are
+    // written once, normalised; otherwise the channel's last block reads them back
+    constexpr int kRegions = PAIR ? WPB / 2 : WPB;
+    cp.status = pl->d_status;
+    cp.flags = pl->d_stream_flags; cp.epoch = ++pl->stream_epoch;
+    cp.wait_mode = (state != nullptr && ngroups <= bpc * kRegions && ngroups <= 64 && grid <= pl->stream_slots && !debug_switches().no_stream_wait) ? 1 : 0;
+    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "", cp.wait_mode ? ", wait" : "");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -1186,6 +1202,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_atab16) (void)hipFree(p->d_atab16);
     if (p->d_stream_arrive) (void)hipFree(p->d_stream_arrive);
     if (p->d_stream_pieces) (void)hipFree(p->d_stream_pieces);
+    if (p->d_stream_flags) (void)hipFree(p->d_stream_flags);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
@@ -1693,6 +1710,11 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
     if (hist + chunk > 0x7fffffffLL || static_cast<long long>(chunk) * 2 * p->K >= 0x7fffffffLL)
         return fail(HSSFSST_EINVAL, "stream_step: chunk too large");
     if (p->K == 0) return 0;
+    if (p->h_status && *p->h_status != 0u) {             // an earlier step's wait between blocks gave up (see hssfsst_plan_check)
+        const unsigned code = *p->h_status;
+        *p->h_status = 0u;
+        return fail(HSSFSST_EHIP, "stream_step: an earlier step gave up waiting inside its launch (code %u); its output is invalid", code);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEVICE_SCOPE(p->device);
     // one launch for the whole step where the transform is the wide-store MFMA kernel in one-group chunks (nwin 256 / 512, an even
@@ -1701,22 +1723,50 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
                             (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                             static_cast<long long>(channels) * ((chunk + 15) / 16) < 0x7fffffffLL;
     int launched = 0;
+    float* mirror = nullptr;
     if (one_launch) {
-        if (!x_on_device)
-            HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
-                                     static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyHostToDevice, st));
+        // host samples in PINNED memory are read by the kernel where they lie (32 KiB per step over the link: no copy operation
+        // in front of the launch); pageable memory is copied into the tape first and the kernel reads it there
         const float* xd = x_on_device ? x_new : nullptr;
+        if (!x_on_device) {
+            for (int k = 0; k < 2 && !xd; ++k)
+                if (p->pin_host[k] == x_new) xd = p->pin_dev[k];
+            if (!xd) {
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, const_cast<float*>(x_new), 0) == hipSuccess && dp) {
+                    xd = static_cast<const float*>(dp);
+                    p->pin_host[p->pin_next] = x_new; p->pin_dev[p->pin_next] = xd; p->pin_next ^= 1;
+                } else (void)hipGetLastError();
+            }
+            if (!xd)
+                HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
+                                         static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyHostToDevice, st));
+        }
+        // a pinned host destination is written by the kernel itself (the last block of a channel stores the normalised chunk to
+        // both places): no copy operation behind the launch either
+        if (out_host && (reinterpret_cast<uintptr_t>(out_host) & 15) == 0) {
+            for (int k = 0; k < 2 && !mirror; ++k)
+                if (p->pin_out_host[k] == out_host) mirror = p->pin_out_dev[k];
+            if (!mirror) {
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, out_host, 0) == hipSuccess && dp) {
+                    mirror = static_cast<float*>(dp);
+                    p->pin_out_host[p->pin_out_next] = out_host; p->pin_out_dev[p->pin_out_next] = mirror; p->pin_out_next ^= 1;
+                } else (void)hipGetLastError();
+            }
+        }
         // (wave pairs: the step's latency is one group's; regions of a block = 2)
         if (debug_switches().no_pair)
-            launched = (p->nt == 32) ? launch_stream<32, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st)
-                                     : launch_stream<16, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st);
+            launched = (p->nt == 32) ? launch_stream<32, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, mirror, st)
+                                     : launch_stream<16, 16, 4, false>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, mirror, st);
         else
-            launched = (p->nt == 32) ? launch_stream<32, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st)
-                                     : launch_stream<16, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, st);
+            launched = (p->nt == 32) ? launch_stream<32, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, mirror, st)
+                                     : launch_stream<16, 16, 4, true>(p, tape + (pos - hist), tape_len, xd, x_stride, channels, chunk, out, state, mirror, st);
         if (launched < 0) return launched;
-        if (launched == 0 && x_on_device)
+        if (launched == 0 && xd)                         // (not this kernel's shape after all: the chunk goes into the tape by a copy)
             HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
-                                     static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyDeviceToDevice, st));
+                                     static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels),
+                                     x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     } else {
         HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
                                  static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels),
@@ -1732,7 +1782,9 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
             HIP_TRY(hipGetLastError());
         }
     }
-    if (out_host) {
+    if (out_host && launched == 1 && mirror) {
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (out_host) {
         HIP_TRY(hipMemcpyAsync(out_host, out, static_cast<size_t>(channels) * chunk * 2 * p->K * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
