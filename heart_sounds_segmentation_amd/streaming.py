@@ -19,9 +19,12 @@ transforms the last ``nwin - 1 + chunk`` samples in place (``x_stride`` = tape l
 tape is full (every ``slots`` steps) the last ``nwin - 1`` samples are copied back to its start.  The
 feature output and the pinned host staging buffers of ``step_host`` are preallocated too.
 
-A step is ONE native call, ``hssfsst_stream_step`` (include/hssfsst.h): strided copy of the chunk into the tape
-(straight from pinned host memory in ``step_host``), the transform, one launch that merges the running moments and
-normalises with them, and -- ``step_host`` -- the copy back plus the one synchronisation.
+A step is ONE native call, ``hssfsst_stream_step`` (include/hssfsst.h), and for window lengths 256 / 512 with an even band of
+at most 24 rows (BASELINE config 5) ONE kernel launch: the kernel appends the chunk to the tape (reading it where it lies,
+pinned host memory included), transforms it, forms every 16-frame group's float64 moment sums from the registers that hold its
+features, and the last block of a channel merges the running moments and normalises the chunk -- into the device buffer and,
+``step_host``, straight into the pinned host buffer; what remains of ``step_host`` is the one synchronisation.  Other shapes
+take copy + transform + one merge-and-normalise launch; both routes give the same bits.
 """
 from __future__ import annotations
 
@@ -59,6 +62,13 @@ class StreamingFSST:
         self._pin_out = None
         self._keep = None
         self._pin_ring = None
+
+    def last_kernel(self) -> str:
+        """The transform kernel the last step ran (``hssfsst_plan_last_kernel`` of this stream's plan): one launch per step
+        reads ``fsst_core128_kernel<..., stream, pairs> [...]``."""
+        buf = ctypes.create_string_buffer(160)
+        _lib.check(_lib.lib().hssfsst_plan_last_kernel(self._plan.handle, buf, len(buf)), "hssfsst_plan_last_kernel")
+        return buf.value.decode()
 
     # kept for callers / tests that looked at the history of the first implementation
     @property

@@ -452,6 +452,103 @@ def test_streaming_matches_offline(oracle_mod):
         assert (y[..., :22] - want).abs().max() < 2e-4 * want.abs().max()
 
 
+_STREAM_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from scipy.signal import get_window
+from heart_sounds_segmentation_amd import synth
+from heart_sounds_segmentation_amd.streaming import StreamingFSST
+outs = []
+for fs, N, chunk, ch, steps in ((4000, 512, 128, 64, 5), (1000, 256, 48, 3, 6), (4000, 512, 80, 300, 3)):
+    w = get_window(("kaiser", 0.5), N, fftbins=False)
+    band = (25, 200) if N == 512 else (30, 50)           # even bands of <= 24 rows: the wide-store epilogue
+    x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=N + ch) + 0.1
+    st = StreamingFSST(ch, fs, w, truncate_freq=band, chunk=chunk, normalize=True, slots=2)
+    sh = StreamingFSST(ch, fs, w, truncate_freq=band, chunk=chunk, normalize=True, slots=3)
+    xd = torch.from_numpy(x).cuda()
+    for i in range(steps):
+        outs.append(st.step(xd[:, i * chunk:(i + 1) * chunk]).cpu().numpy())
+        assert np.array_equal(sh.step_host(x[:, i * chunk:(i + 1) * chunk]), outs[-1])
+    outs.append(st.state.cpu().numpy())
+    assert torch.equal(st.state, sh.state)
+    print(N, ch, st.last_kernel())
+np.savez(sys.argv[1], *outs)
+'''
+
+
+def test_stream_step_variants_are_bit_identical(tmp_path):
+    """One launch per step (fsst_core128_kernel<STREAM>: tape append, transform, the groups' float64 sums, the channel's last block
+    merges and normalises), with and without wave pairs, and the three-launch route give the same bits -- features and running
+    moments -- on BASELINE config 5's shape, on a 256-point window with a ragged last group and on more channels than CUs
+    (one block per channel, several tickets per wave region)."""
+    res = {}
+    for tag, env in (("default", {}), ("no_pair", {"HSSFSST_NO_PAIR": "1"}), ("three_launches", {"HSSFSST_NO_STREAM_FUSE": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        log = _run_child(env, _STREAM_CHILD.replace("sys.argv[1]", repr(out)))
+        res[tag] = (np.load(out), log)
+    ref, log = res["default"]
+    assert "stream, pairs" in log and "stream" not in res["three_launches"][1], (log, res["three_launches"][1])
+    assert "stream" in res["no_pair"][1] and "pairs" not in res["no_pair"][1], res["no_pair"][1]
+    for tag in ("no_pair", "three_launches"):
+        for k in ref.files:
+            assert np.array_equal(ref[k], res[tag][0][k]), (tag, k)
+    assert all(np.isfinite(ref[k]).all() for k in ref.files)
+
+
+def test_stream_step_pageable_host_buffers():
+    """hssfsst_stream_step through raw ctypes with PAGEABLE host memory on both sides (the kernel can read / write pinned
+    buffers in place; anything else is copied): the same bits as the device route."""
+    from scipy.signal import get_window
+    from heart_sounds_segmentation_amd.streaming import StreamingFSST
+    fs, N, chunk, ch, steps = 4000, 512, 128, 16, 4
+    w = get_window(("kaiser", 0.5), N, fftbins=False)
+    x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=77)
+    a = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True, slots=8)
+    b = StreamingFSST(ch, fs, w, truncate_freq=BAND, chunk=chunk, normalize=True, slots=8)
+    L = _lib.lib()
+    host_out = np.empty((ch, chunk, 2 * b.K), dtype=np.float32)
+    for i in range(steps):
+        xi = np.ascontiguousarray(x[:, i * chunk:(i + 1) * chunk])
+        ya = a.step(torch.from_numpy(xi).cuda())
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L.hssfsst_stream_step(b._plan.handle, ctypes.c_void_p(b.tape.data_ptr()), b.tape_len, b.pos, ctypes.c_void_p(xi.ctypes.data), chunk, 0,
+                                   ch, chunk, ctypes.c_void_p(b.out.data_ptr()), ctypes.c_void_p(b.state.data_ptr()),
+                                   ctypes.c_void_p(host_out.ctypes.data), stream)
+        _lib.check(rc, "hssfsst_stream_step")
+        b.pos += chunk
+        assert np.array_equal(host_out, ya.cpu().numpy()), i
+        assert torch.equal(a.state, b.state)
+        assert torch.equal(a.tape[:, :a.pos], b.tape[:, :b.pos])
+
+
+@pytest.mark.parametrize("band,n,batch", [((25, 200), 1, 3), ((25, 200), 17, 2), ((25, 210), 100, 2), ((25, 210), 2000, 3), ((25, 200), 1029, 1)])
+def test_moments_merge_any_shape(band, n, batch):
+    """hssfsst_moments_merge sums a chunk in the order of the transform kernels' 16-frame pieces (fsst_kernels.hpp,
+    chunk_moments): any number of frames, even and odd bands, against float64 numpy; two chunks merged == one."""
+    tf = FSST(1000, KAISER, truncate_freq=band, stack=True)
+    plan = tf._plan(0, _lib.MODE_STACK_UNNORM)
+    K = plan.K
+    rng = np.random.default_rng(n + K)
+    F = (rng.standard_normal((batch, n, 2 * K)) * 3.0 + 1.5).astype(np.float32)
+    Fd = torch.from_numpy(F).cuda()
+    L = _lib.lib()
+    state = torch.zeros(batch, 6, dtype=torch.float64, device="cuda")
+    assert L.hssfsst_moments_merge(plan.handle, ctypes.c_void_p(Fd.data_ptr()), batch, n, ctypes.c_void_p(state.data_ptr()), None) == 0
+    st = state.cpu().numpy()
+    F64 = F.astype(np.float64)
+    for b in range(batch):
+        for blk, off in ((F64[b, :, :K], 0), (F64[b, :, K:], 3)):
+            assert st[b, off] == blk.size
+            assert abs(st[b, off + 1] - blk.mean()) <= 1e-12 * max(1.0, abs(blk.mean()))
+            m2 = ((blk - blk.mean()) ** 2).sum()
+            assert abs(st[b, off + 2] - m2) <= 1e-10 * max(m2, 1e-30) + 1e-18
+    if n >= 17:                                          # the same chunk again: counts double, mean stays, M2 doubles
+        assert L.hssfsst_moments_merge(plan.handle, ctypes.c_void_p(Fd.data_ptr()), batch, n, ctypes.c_void_p(state.data_ptr()), None) == 0
+        st2 = state.cpu().numpy()
+        assert np.array_equal(st2[:, [0, 3]], 2 * st[:, [0, 3]])
+        assert np.allclose(st2[:, [1, 4]], st[:, [1, 4]], rtol=1e-13, atol=0) and np.allclose(st2[:, [2, 5]], 2 * st[:, [2, 5]], rtol=1e-12, atol=0)
+
+
 def test_stream_step_equals_separate_calls():
     """hssfsst_stream_step (copy into the tape + transform + ONE merge-and-normalise launch, optionally D2H + wait)
     gives bit for bit what hssfsst_exec_frames + hssfsst_moments_merge + hssfsst_normalize_running give, on the

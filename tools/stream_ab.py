@@ -30,4 +30,4 @@ for i in range(350):
     c = np.ascontiguousarray(xh[:, (i % 64) * 128:(i % 64 + 1) * 128])
     t0 = time.perf_counter(); st.step_host(c); lat.append(time.perf_counter() - t0)
 lat = np.array(lat[50:]) * 1e6
-print(f"{os.path.basename(lib):28s} {np.median(rates) / 1e3:6.2f} k steps/s (min {min(rates) / 1e3:.2f}, max {max(rates) / 1e3:.2f});  host-visible {np.median(lat):6.1f} us median, {np.percentile(lat, 99):6.1f} p99   [{st.tf.last_kernel()}]")
+print(f"{os.path.basename(lib):28s} {np.median(rates) / 1e3:6.2f} k steps/s (min {min(rates) / 1e3:.2f}, max {max(rates) / 1e3:.2f});  host-visible {np.median(lat):6.1f} us median, {np.percentile(lat, 99):6.1f} p99   [{st.last_kernel()}]")

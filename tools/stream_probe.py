@@ -30,7 +30,7 @@ for rep in range(50):
 names = ["prologue", "main loop", "arrival", "merged", "normalised", "tile staged (last group)", "passes done (last group)", "end"]
 for k, n in enumerate(names):
     print(f"{n:28s} {acc[k, 0] / 100.0 / max(1, acc[k, 1]):8.2f} us  (mean over {int(acc[k, 1])} waves)")
-print(st.tf.last_kernel() if hasattr(st.tf, "last_kernel") else "")
+print(st.last_kernel())
 t0 = time.perf_counter()
 for i in range(2000):
     st.step(x[:, (i % 64) * 128:(i % 64 + 1) * 128], copy=False)
