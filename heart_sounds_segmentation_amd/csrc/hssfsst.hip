@@ -608,16 +608,32 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     return 1;
 }
 
-// Canonical-band kernels (fsst_canon128.hpp): nwin = 128, the band of /root/reference/main.py:153-158 (rows 4..25), STACK /
-// STACK_UNNORM.  kCanonKlo / kCanonK are the one instantiated band; every other band keeps fsst_core128_kernel.
-constexpr int kCanonKlo = 4, kCanonK = 22;
-using CanonBand = hssfsst::CanonCfg<kCanonKlo, kCanonK>;
+// Canonical-class kernels (fsst_canon128.hpp): nwin = 128, STACK / STACK_UNNORM, the kept band a compile-time constant.  Two bands
+// are instantiated: rows 4..25 = [25, 200] Hz at fs = 1000 (/root/reference/main.py:153-158, the reference's own configuration) and
+// rows 2..25 = [25, 400] Hz at fs = 2000 -- the pass band of the Springer / Schmidt heart-sound segmenters on recordings at
+// PhysioNet 2016's native rate (/root/reference/hss/datasets/heart_sounds.py:36-113 loads them un-resampled).  Every other band keeps
+// fsst_core128_kernel.  (A third band is one line here: the template takes any even band of <= 24 rows inside rows 0..31.)
+constexpr int kCanonBands[][2] = {{4, 22}, {2, 24}};
+constexpr int kCanonKlo = kCanonBands[0][0], kCanonK = kCanonBands[0][1];
 
-bool plan_is_canon(const hssfsst_plan* pl)
+int canon_band(const hssfsst_plan* pl)                   // index into kCanonBands, or -1
 {
-    const bool off = debug_switches().no_canon;            // A/B and cross-check tests
-    return !off && pl->d_atab16 && pl->nwin == 128 && pl->klo == kCanonKlo && pl->K == kCanonK &&
-           (pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM);
+    if (debug_switches().no_canon || !pl->d_atab16 || pl->nwin != 128) return -1;     // (no_canon: A/B and cross-check tests)
+    if (!(pl->mode == HSSFSST_MODE_STACK || pl->mode == HSSFSST_MODE_STACK_UNNORM)) return -1;
+    for (int i = 0; i < static_cast<int>(sizeof(kCanonBands) / sizeof(kCanonBands[0])); ++i)
+        if (pl->klo == kCanonBands[i][0] && pl->K == kCanonBands[i][1]) return i;
+    return -1;
+}
+bool plan_is_canon(const hssfsst_plan* pl) { return canon_band(pl) >= 0; }
+// f(KLO, KC) with the plan's band as integral constants
+template <class F>
+int canon_dispatch(const hssfsst_plan* pl, F&& f)
+{
+    switch (canon_band(pl)) {
+    case 0: return f(std::integral_constant<int, kCanonBands[0][0]>{}, std::integral_constant<int, kCanonBands[0][1]>{});
+    case 1: return f(std::integral_constant<int, kCanonBands[1][0]>{}, std::integral_constant<int, kCanonBands[1][1]>{});
+    default: return fail(HSSFSST_EINVAL, "canon_dispatch: not a canonical-class plan");
+    }
 }
 
 hssfsst::CanonParams canon_params(const hssfsst_plan* pl, const hssfsst::Core128Params& cp)
@@ -631,11 +647,13 @@ hssfsst::CanonParams canon_params(const hssfsst_plan* pl, const hssfsst::Core128
     return q;
 }
 
-int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
+template <int KLO, int KC>
+int launch_canon_band(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
     constexpr int WPB = 16;
-    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + static_cast<size_t>(WPB) * CanonBand::wave_floats()) * sizeof(float);
-    auto kern = hssfsst::fsst_canon_kernel<kCanonKlo, kCanonK, false>;
+    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    static_assert((hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + 16 * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float) <= 160 * 1024, "16 wave regions must fit");
+    auto kern = hssfsst::fsst_canon_kernel<KLO, KC, false>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->canon_slots == 0) {
@@ -651,22 +669,29 @@ int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nch
     // (a gated launch -- the fallback behind a team launch -- almost always finds its gate closed: a quarter of the chip keeps
     //  the empty launch at ~2 us instead of ~4; when it does run, the GPU is shared anyway)
     if (pl->gate != nullptr && blocks > 64) blocks = 64;
-    if (pl->gate == nullptr) name_kernel(pl, WPB, blocks, "fsst_canon_kernel<%d, %d, false>", kCanonKlo, kCanonK);
+    if (pl->gate == nullptr) name_kernel(pl, WPB, blocks, "fsst_canon_kernel<%d, %d, false>", KLO, KC);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int launch_canon(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
+{
+    return canon_dispatch(pl, [&](auto KL, auto KN) { return launch_canon_band<decltype(KL)::value, decltype(KN)::value>(pl, cp, nchunks, st); });
 }
 
 // One CU per signal with the z-score in the same launch (see launch_fused128): 1 = launched, 0 = take another path
 // gated = the fallback queued behind a team launch (pl->gate set): any batch size -- the block count is what a launch that
 // almost always finds its gate closed should cost, not what would be fast.
-int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st, bool gated = false)
+template <int KLO, int KC>
+int launch_canon_fused_band(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batch, int ngroups, hipStream_t st, bool gated)
 {
     constexpr int WPB = 16, GPC = hssfsst::kCanonTileFrames / 16;
     if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + GPC - 1) / GPC < hssfsst::kFusedMinChunks) return 0;
-    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFusedFloats + static_cast<size_t>(WPB) * CanonBand::wave_floats()) * sizeof(float);
-    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    auto kern = hssfsst::fsst_canon_kernel<kCanonKlo, kCanonK, true>;
+    constexpr size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFusedFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    // (rows 2..25: 16 wave regions of 8.6 kB and the two signals' partials do not fit the 160 KiB together: team kernel or two launches)
+    if constexpr (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    else {
+    auto kern = hssfsst::fsst_canon_kernel<KLO, KC, true>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
     if (pl->fused_slots == 0) {
@@ -684,10 +709,15 @@ int launch_canon_fused(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t batc
     else if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
-    if (!gated) name_kernel(pl, WPB, grid, "fsst_canon_kernel<%d, %d, true>", kCanonKlo, kCanonK);
+    if (!gated) name_kernel(pl, WPB, grid, "fsst_canon_kernel<%d, %d, true>", KLO, KC);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, canon_params(pl, cp));
     HIP_TRY(hipGetLastError());
     return 1;
+    }
+}
+int launch_canon_fused(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st, bool gated = false)
+{
+    return canon_dispatch(pl, [&](auto KL, auto KN) { return launch_canon_fused_band<decltype(KL)::value, decltype(KN)::value>(pl, cp, batch, ngroups, st, gated); });
 }
 
 int plan_next_event(hssfsst_plan* p, hipEvent_t* out_ev)
@@ -745,7 +775,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool hold = pl->offset_hold > 0 && !team_only;
         if (hold) --pl->offset_hold;
         if (!no_team && !hold && canon16) {
-            rc = launch_team16<kCanonKlo, kCanonK, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st);
+            rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
                 // them apart: fsst_team16.hpp "Progress"): the same exec is queued behind it, every kernel of it gated on the

@@ -729,6 +729,40 @@ def test_zpath_preference_is_bit_identical(batch):
         tf.set_zpath("fastest")
 
 
+@pytest.mark.parametrize("n,batch", [(2000, 300), (1999, 7), (130, 33), (4000, 5)])
+def test_second_canonical_band(oracle_mod, n, batch):
+    """The canonical-class kernels are a template over the kept band, not one benchmark point: [25, 400] Hz at fs = 2000 (rows
+    2..25 of a 128-point window: PhysioNet 2016's native rate, the Springer / Schmidt pass band) runs fsst_canon_kernel<2, 24, .>
+    and fsst_team16_kernel<2, 24, 16, 2> -- parity with the oracle, the z-score paths bit-identical, offsets and odd lengths
+    included; the general kernels (HSSFSST_NO_CANON's route, here: the raw transform of the same rows) agree to the gate."""
+    fs, band = 2000, (25, 400)
+    X = synth.pcg_windows(batch, n, fs=fs, seed=n + batch)
+    X[1] += 2.5                                          # rides on an offset (fsst_canon128.hpp "Offsets")
+    Xd = torch.from_numpy(X).cuda()
+    tf = FSST(fs, KAISER, truncate_freq=band, stack=True)
+    assert tf.band() == (2, 24)
+    ref = None
+    for zp in ("two_launch", "team", "auto"):
+        tf.set_zpath(zp)
+        got = tf.batch(Xd)
+        path, name = tf.check(), tf.last_kernel()
+        if zp == "two_launch":
+            assert path == 0 and name.startswith("fsst_canon_kernel<2, 24, false>"), (path, name)
+        if zp == "team" and -(-n // 16) <= 128:
+            assert name.startswith("fsst_team16_kernel<2, 24, 16, 2>"), name
+        if ref is None:
+            ref = got.clone()
+        else:
+            assert torch.equal(got, ref), zp
+    o, hd = oracle_mod.features(X[:4], fs, KAISER, band, "stack", return_halfdist=True)
+    for b in range(4):
+        parity.check(ref[b].cpu().numpy(), o[b], hd[b], 0, what=f"band (2, 24) signal {b}")
+    U = tf.unnormalized(Xd[:2]).cpu().numpy()            # the same kernels without the z-score
+    raw = FSST(fs, KAISER, truncate_freq=band).batch(Xd[:2]).cpu().numpy()      # (2, K, n) complex: fsst_core128_kernel
+    want = np.concatenate([raw.real.transpose(0, 2, 1), raw.imag.transpose(0, 2, 1)], axis=-1)
+    assert np.abs(U - want).max() <= 2e-6 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("nwin,n,batch", [(256, 2000, 256), (256, 2000, 300), (256, 1504, 512), (256, 1999, 256), (512, 2000, 256),
                                           (128, 2000, 256)])
 def test_general_band_single_launch_zscore_is_bit_identical(oracle_mod, nwin, n, batch):
