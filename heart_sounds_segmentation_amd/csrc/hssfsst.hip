@@ -411,7 +411,7 @@ int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const fl
     constexpr int kRegions = PAIR ? WPB / 2 : WPB;
     cp.status = pl->d_status;
     cp.flags = pl->d_stream_flags; cp.epoch = ++pl->stream_epoch;
-    cp.wait_mode = (state != nullptr && ngroups <= bpc * kRegions && ngroups <= 64 && grid <= pl->stream_slots && !debug_switches().no_stream_wait) ? 1 : 0;
+    cp.wait_mode = (HSS_STREAM_WAIT && state != nullptr && ngroups <= bpc * kRegions && ngroups <= 64 && grid <= pl->stream_slots && !debug_switches().no_stream_wait) ? 1 : 0;
     name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "", cp.wait_mode ? ", wait" : "");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
