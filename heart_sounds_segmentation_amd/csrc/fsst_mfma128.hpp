@@ -308,14 +308,35 @@ __device__ __forceinline__ void wave_sync()
 // Moves a source k' -> row in a frame's displaced plane: the own plane holds V in the source's own column
 // (unconditional store), so V is taken out again there, added at `row` and -- conjugated -- at the negative-frequency
 // twin's row nwin - row (oracle/fsst_oracle.c step 6: two-sided cyclic scatter, one-sided rows kept).
-template <int NWIN, bool LANE_OWNS = false>
+// The odd wave of a PAIR (fsst_core128_kernel) does not add into the displaced plane while the even wave does: it LISTS its
+// additions -- (cell, re, im) in program order, lanes in order (ballot prefix: no atomics) -- and the even wave replays the list
+// behind its own additions: the plane receives every addition in the order of the one-wave kernel, whichever wave runs faster.
+constexpr int kPairListCap = 256;
+struct PairList {
+    int* cell;            // [kPairListCap] float index into the displaced plane (re component; im = + 1)
+    f2* val;              // [kPairListCap]
+    int* cnt;             // (in LDS) additions listed; > kPairListCap: entries were dropped, the group is redone without the list
+    int rowoff;           // this lane's frame row of the displaced plane, in cells
+};
+template <int NWIN, bool LANE_OWNS = false, bool LIST = false>
 __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V,
-                                            f2* own_cell = nullptr, bool stored = false)
+                                            f2* own_cell = nullptr, bool stored = false, PairList* pl = nullptr)
 {
     auto add = [&](int idx, float re, float im) {
-        float* q = reinterpret_cast<float*>(row_disp + idx);
-        __hip_atomic_fetch_add(q, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(q + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (LIST) {
+            // (the count lives in LDS: a variable updated under a divergent branch would be per-lane, stale in the lanes that
+            //  did not take it; the first active lane reserves the slots of all of them)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(true);      // the lanes that add here, in lane order
+            const int below = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u)));
+            int base = 0;
+            if (below == 0) base = __hip_atomic_fetch_add(pl->cnt, static_cast<int>(__builtin_popcountll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int slot = __builtin_amdgcn_readfirstlane(base) + below;
+            if (slot < kPairListCap) { pl->cell[slot] = 2 * (pl->rowoff + idx); pl->val[slot] = f2{re, im}; }
+        } else {
+            float* q = reinterpret_cast<float*>(row_disp + idx);
+            __hip_atomic_fetch_add(q, re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(q + 1, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     if (row == kpi) return;                             // rounds back into its own row after all
     const int own = kpi - klo, idx = row - klo;
@@ -341,9 +362,9 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
 // rounding tie, which are queued for resolve_ties().  `row_disp` points at this lane's frame row (frame j of the
 // group) in the displaced plane.
-template <int NWIN, int ERRMUL = 1>
+template <int NWIN, int ERRMUL = 1, bool LIST = false>
 __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* tq, int klo, int K, int kpi, int j,
-                                                 float num, float den, f2 V, float R2, f2* own_cell, bool stored)
+                                                 float num, float den, f2 V, float R2, f2* own_cell, bool stored, PairList* pl = nullptr)
 {
     float shift = num * __builtin_amdgcn_rcpf(den);
     if (!(fabsf(shift) <= 1.0e6f)) shift = 0.0f;        // NaN / inf / absurd -> 0 (fsst.m: ~isfinite)
@@ -363,7 +384,7 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
         return;
     }
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    move_source<NWIN, true>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
+    move_source<NWIN, true, LIST>(row_disp, flag, klo, K, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored, pl);
 }
 
 // The whole wave, after the group's spectra: every undecided cell's bin of V and Vd' by a float64 DFT of its frame
@@ -735,9 +756,10 @@ __device__ __forceinline__ void resolve_ties(int* tq, const float* xg, f2* disp_
 // The two sources of one stripe (classes a and b of this lane) with ONE rare-path branch for both (a branch per
 // source -- v_cmp + s_and_saveexec + s_cbranch + s_or each -- measured 1.8 % slower; one branch per two stripes: no
 // further gain).
-template <int S, int RQ, int NWIN>
+template <int S, int RQ, int NWIN, bool LIST = false>
 __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 tiny, f2* ownA, f2* ownB, bool store,
-                                               f2* row_disp, int* flag, int* tq, int j, int klo, int K, int rA, int rB, float R2, float& mx)
+                                               f2* row_disp, int* flag, int* tq, int j, int klo, int K, int rA, int rB, float R2, float& mx,
+                                               PairList* pl = nullptr)
 {
     const f2 a1 = mix_re(XA, PA), a2 = mix_im(XA, PA);
     const f2 b1 = mix_re(XB, PB), b2 = mix_im(XB, PB);
@@ -761,8 +783,8 @@ __device__ __forceinline__ void process_stripe(f2 XA, f2 PA, f2 XB, f2 PB, f2 ti
 #endif
     const bool ma = fabsf(dna.y) >= kStay * dna.x, mb = fabsf(dnb.y) >= kStay * dnb.x;
     if (ma | mb) {                                      // skipped when no lane moved (execz)
-        if (ma) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2, ownA, store);
-        if (mb) displaced_source<NWIN>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2, ownB, store);
+        if (ma) displaced_source<NWIN, 1, LIST>(row_disp, flag, tq, klo, K, rA + RQ * S, j, dna.y, dna.x, f2{a1.x, a2.x}, R2, ownA, store, pl);
+        if (mb) displaced_source<NWIN, 1, LIST>(row_disp, flag, tq, klo, K, rB + RQ * S, j, dnb.y, dnb.x, f2{b1.x, b2.x}, R2, ownB, store, pl);
     }
 }
 // ------------------------------------------------------------------------------------------------
@@ -810,14 +832,16 @@ __device__ unsigned long long g_stream_probe[kStreamProbeWaves * 8];      // [wa
 #define SPROBE(k) do { } while (0)
 #endif
 // PAIR (nwin 256 / 512, whose transform is two passes over the same 16 frames): TWO waves share one wave region -- wave 2 r does
-// pass 0 of region r's group, wave 2 r + 1 pass 1: fold and spectra at the same time, the odd wave's sources after the even wave's
-// (the order of the additions into the displaced plane is the one-wave kernel's: same bits); the even wave then runs everything
-// that follows the passes.  The pair
+// pass 0 of region r's group, wave 2 r + 1 pass 1, at the same time; the passes write disjoint columns of the own plane, and the
+// odd wave LISTS its additions into the displaced plane instead of making them (PairList): the even wave replays the list behind
+// its own additions, so the plane receives every addition in the order of the one-wave kernel -- the same bits whoever runs
+// faster.  The even wave then runs everything that follows the passes.  The pair
 // meets through two phase words in LDS (pair_sync: LDS operations of a wave are executed in order, so a phase word written
 // after a wave's data is seen after it): twice the waves on the same LDS -- 6 instead of 3 per CU for nwin 512 with 90 kept
 // rows -- and half the latency of a lone group (one streaming step).
 constexpr unsigned kPairSpinLimit = 1u << 24;       // looks at the partner's phase word before a pair's wait ends on its own (~1 s)
-constexpr int kPairFloats = 4 + 64;          // [0..1] phase words, [2] the pair's ticket, [4..67] the odd wave's per-lane max |V|^2
+constexpr int kPairFloats = 4 + 64 + 3 * 256;  // [0..1] phase words, [2] the pair's ticket, [3] the odd wave's list count, [4..67] its per-lane
+                                             // max |V|^2, then its list of additions (PairList: 256 cells, 256 values)
 template <int NT, int RQ, int FPW, bool FAST, int WPB, int S1C, bool FUSED = false, bool STREAM = false, bool PAIR = false>
 __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : WPB == 12 ? 3 : 2)) void fsst_core128_kernel(Core128Params p)
 {
@@ -866,6 +890,8 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
     int* tq = flag + 4;                                                       // rounding-tie bitmap (tie_words(NWIN))
     int* pw = tq + tie_words(NWIN);                                           // PAIR: phase words, ticket
     float* pmx = reinterpret_cast<float*>(pw + 4);                            // PAIR: the odd wave's per-lane max
+    PairList plist{pw + 4 + 64, reinterpret_cast<f2*>(pw + 4 + 64 + kPairListCap), pw + 3, 0};      // PAIR: the odd wave's additions
+    bool pordered = false;                               // PAIR: a list overflowed: this pair forms the odd wave's sources behind the even wave's
     if constexpr (PAIR) { if (lane < 4) pw[lane] = 0; }
     int pphase = 0;
     auto pair_sync = [&]() {
@@ -1271,18 +1297,43 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
         }
 #else
         // ---- one-sided sources of this lane: classes rA (array a) and rB (array b)
+        bool listed = false;
         if constexpr (PAIR && pz == 1) {
-            // the odd wave forms its sources once the even wave is through its pass (it has arrived at the sync behind it): the
-            // displaced plane then receives the additions in the order of the one-wave kernel -- pass 0's, then pass 1's --, the
-            // same bits whoever runs faster; what overlaps is the matrix-pipe fold and the 16 / 32-point spectra
-            for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
-                int v = 0;
-                if (lane == 0) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) break;
-                __builtin_amdgcn_s_sleep(1);
+            if (!pordered) {
+                // the odd wave's sources at the same time as the even wave's: its additions into the displaced plane go to a list
+                // (PairList) that the even wave replays behind its own -- the order of the one-wave kernel, the same bits
+                listed = true;
+                plist.rowoff = j * LDF;
+                if (lane == 0) pw[3] = 0;
+                wave_sync();
+        static_for<NT / 2>([&](auto SS) {
+                constexpr int s = decltype(SS)::value;
+                // partner of a[s]: class 0 -> a[(NT-s) mod NT];  else b[NT-1-s].  partner of b[s]: class RQ/2 -> b[NT-1-s]; else a[NT-1-s]
+                const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
+                f2 PA, PB;
+                if constexpr (pz == 0) {
+                    PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
+                    PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+                } else {                                         // no self-conjugate class in the later passes
+                    PA = pb; PB = pa;
+                }
+                const bool st = (s >= s0) && (s <= s1);
+                process_stripe<s, RQ, NWIN, true>(za[s], PA, zb[s], PB, tiny, ownA + RQ * s, ownB + RQ * s, st, row_disp, flag, tq, j, klo, K, rAi, rBi, R2, mx, &plist);
+            });
+            } else {
+                // (a list overflowed earlier: the odd wave forms its sources once the even wave is through its pass -- it has arrived
+                //  at the sync behind it --, adding into the plane itself: the same order)
+                for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
+                    int v = 0;
+                    if (lane == 0) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                wave_sync();
+                if (lane == 0) pw[3] = 0;
             }
-            wave_sync();
         }
+        if (!listed)
         static_for<NT / 2>([&](auto SS) {
             constexpr int s = decltype(SS)::value;
             // partner of a[s]: class 0 -> a[(NT-s) mod NT];  else b[NT-1-s].  partner of b[s]: class RQ/2 -> b[NT-1-s]; else a[NT-1-s]
@@ -1304,9 +1355,38 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
 #endif
         };
         if constexpr (PAIR) {
-            if (role == 0) one_pass(std::integral_constant<int, 0>{});
-            else { one_pass(std::integral_constant<int, 1>{}); pmx[lane] = mx; }
-            pair_sync();                                     // both passes are in the planes
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                mx = 0.0f;
+                if (role == 0) one_pass(std::integral_constant<int, 0>{});
+                else { one_pass(std::integral_constant<int, 1>{}); pmx[lane] = mx; }
+                pair_sync();                                 // both passes are in the planes, the odd wave's additions in its list
+                const int cnt = __builtin_amdgcn_readfirstlane(pw[3]);
+                if (cnt <= kPairListCap) {
+                    if (role == 0 && cnt > 0) {              // replay: list order = the one-wave kernel's order of pass 1
+                        float* dpl = reinterpret_cast<float*>(disp_base);
+                        for (int base = 0; base < cnt; base += 64) {
+                            const int i = base + lane;
+                            if (i < cnt) {
+                                float* q = dpl + plist.cell[i];
+                                const f2 v = plist.val[i];
+                                __hip_atomic_fetch_add(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                        wave_sync();
+                    }
+                    break;
+                }
+                // (rare) more additions than the list holds: the planes are cleaned and the group is done again with the odd wave's
+                // sources behind the even wave's -- for the rest of this pair's launch (a tonal input that moves everything)
+                if (role == 0) {
+                    for (int i = lane; i < 16 * LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
+                    if (lane == 0) flag[0] = 0;
+                    wave_sync();
+                }
+                pordered = true;
+                pair_sync();
+            }
             if (role == 0) mx = fmaxf(mx, pmx[lane]);
         } else {
             static_for<NPASS>(one_pass);

@@ -253,8 +253,6 @@ struct hssfsst_plan {
     unsigned* d_stream_arrive = nullptr; int stream_arrive_cap = 0;   // streaming step: blocks delivered per channel
     double* d_stream_pieces = nullptr; long long stream_pieces_cap = 0;   // and the groups' float64 sums [channels][groups][4]
     unsigned* d_stream_flags = nullptr; unsigned stream_epoch = 0;        // ... with the step they belong to (wait mode)
-    const float* pin_host[2] = {nullptr, nullptr}; const float* pin_dev[2] = {nullptr, nullptr}; int pin_next = 0;   // pinned host chunks seen (device view)
-    float* pin_out_host[2] = {nullptr, nullptr}; float* pin_out_dev[2] = {nullptr, nullptr}; int pin_out_next = 0;   // and pinned host destinations
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
@@ -823,6 +821,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         int rc = 0;
         if (nt == 16 && fixed + 8 * per_wave <= room)
             rc = canon ? launch_fused_general<16, 16, 8, 3>(pl, cp, batch, ngroups, st) : launch_fused_general<16, 16, 8, -1>(pl, cp, batch, ngroups, st);
+        else if (nt == 32 && !debug_switches().no_pair) rc = 0;       // (512 points: two launches with wave pairs are faster -- 2.66 vs 3.0 ms per 1024 windows)
         else if (nt == 32 && fixed + 8 * per_wave <= room) rc = launch_fused_general<32, 16, 8, -1>(pl, cp, batch, ngroups, st);
         else if (nt == 32 && fixed + 6 * per_wave <= room) rc = 0;                       // (6 waves: two launches)
         else if (nt == 32 && fixed + 4 * per_wave <= room) rc = launch_fused_general<32, 16, 4, -1>(pl, cp, batch, ngroups, st);
@@ -1759,15 +1758,10 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
         // in front of the launch); pageable memory is copied into the tape first and the kernel reads it there
         const float* xd = x_on_device ? x_new : nullptr;
         if (!x_on_device) {
-            for (int k = 0; k < 2 && !xd; ++k)
-                if (p->pin_host[k] == x_new) xd = p->pin_dev[k];
-            if (!xd) {
-                void* dp = nullptr;
-                if (hipHostGetDevicePointer(&dp, const_cast<float*>(x_new), 0) == hipSuccess && dp) {
-                    xd = static_cast<const float*>(dp);
-                    p->pin_host[p->pin_next] = x_new; p->pin_dev[p->pin_next] = xd; p->pin_next ^= 1;
-                } else (void)hipGetLastError();
-            }
+            // (asked at every step: a cached answer would outlive the caller's buffer)
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, const_cast<float*>(x_new), 0) == hipSuccess && dp) xd = static_cast<const float*>(dp);
+            else (void)hipGetLastError();
             if (!xd)
                 HIP_TRY(hipMemcpy2DAsync(tape + pos, static_cast<size_t>(tape_len) * sizeof(float), x_new, static_cast<size_t>(x_stride) * sizeof(float),
                                          static_cast<size_t>(chunk) * sizeof(float), static_cast<size_t>(channels), hipMemcpyHostToDevice, st));
@@ -1775,15 +1769,9 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
         // a pinned host destination is written by the kernel itself (the last block of a channel stores the normalised chunk to
         // both places): no copy operation behind the launch either
         if (out_host && (reinterpret_cast<uintptr_t>(out_host) & 15) == 0) {
-            for (int k = 0; k < 2 && !mirror; ++k)
-                if (p->pin_out_host[k] == out_host) mirror = p->pin_out_dev[k];
-            if (!mirror) {
-                void* dp = nullptr;
-                if (hipHostGetDevicePointer(&dp, out_host, 0) == hipSuccess && dp) {
-                    mirror = static_cast<float*>(dp);
-                    p->pin_out_host[p->pin_out_next] = out_host; p->pin_out_dev[p->pin_out_next] = mirror; p->pin_out_next ^= 1;
-                } else (void)hipGetLastError();
-            }
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, out_host, 0) == hipSuccess && dp) mirror = static_cast<float*>(dp);
+            else (void)hipGetLastError();
         }
         // (wave pairs: the step's latency is one group's; regions of a block = 2)
         if (debug_switches().no_pair)

@@ -459,10 +459,15 @@ from scipy.signal import get_window
 from heart_sounds_segmentation_amd import synth
 from heart_sounds_segmentation_amd.streaming import StreamingFSST
 outs = []
-for fs, N, chunk, ch, steps in ((4000, 512, 128, 64, 5), (1000, 256, 48, 3, 6), (4000, 512, 80, 300, 3)):
-    w = get_window(("kaiser", 0.5), N, fftbins=False)
+for fs, N, chunk, ch, steps in ((4000, 512, 128, 64, 5), (1000, 256, 48, 3, 6), (4000, 512, 80, 300, 3), (4000, 512, 128, 9, 4)):
+    w = get_window(("kaiser", 0.5), N, fftbins=False) if ch != 9 else get_window("hann", N, fftbins=False)
     band = (25, 200) if N == 512 else (30, 50)           # even bands of <= 24 rows: the wide-store epilogue
     x = synth.pcg_windows(ch, chunk * steps, fs=fs, seed=N + ch) + 0.1
+    if ch == 9:                                          # tones under a Hann window: many sources move into the same cells (the order
+        t = np.arange(chunk * steps) / fs                # of the additions into the displaced plane matters to the last bit), more
+        for c in range(ch):                              # than a pair's list holds in some groups
+            x[c] = (np.sin(2 * np.pi * (61.3 + 11.7 * c) * t) + 0.5 * np.sin(2 * np.pi * (143.1 + 3.3 * c) * t + 1.0)
+                    + 0.25 * np.sin(2 * np.pi * (97.9 - 2.1 * c) * t * (1 + 0.2 * t))).astype(np.float32)
     st = StreamingFSST(ch, fs, w, truncate_freq=band, chunk=chunk, normalize=True, slots=2)
     sh = StreamingFSST(ch, fs, w, truncate_freq=band, chunk=chunk, normalize=True, slots=3)
     xd = torch.from_numpy(x).cuda()
@@ -782,7 +787,8 @@ def test_general_band_single_launch_zscore_is_bit_identical(oracle_mod, nwin, n,
     got = tf.batch(X)
     path = tf.check()
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-        want = 1 if (batch in (256, 512) and (n * ref.shape[-1]) % 4 == 0) else 0
+        # (512 points: two launches on wave pairs beat the single launch and are the default)
+        want = 1 if (batch in (256, 512) and (n * ref.shape[-1]) % 4 == 0 and nwin != 512) else 0
         assert path == want, (path, want)
         rq = {128: 8, 256: 16, 512: 16}[nwin]
         assert tf.last_kernel().startswith(f"fsst_core128_kernel<{32 if nwin == 512 else 16}, {rq}, 64, false, ") and tf.last_kernel().split(">")[0].replace(", pairs", "").endswith("true" if want else "false"), tf.last_kernel()
