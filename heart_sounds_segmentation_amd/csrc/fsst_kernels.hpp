@@ -342,13 +342,48 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off, int lane)
 // stats_finish: the part after the per-lane accumulation (lane (blk % 16, q) holds the sum of its blocks' quantity q);
 // split off so that a kernel whose block sums arrive some other way runs the very same
 // instructions on the very same numbers as the two-kernel path.
-__device__ __forceinline__ float4 stats_finish(double acc, double total, int lane)
+// The value of lane (lane ^ OFF), OFF in {4, 8, 16, 32}, without a trip through the LDS crossbar: row rotations (DPP) inside the
+// 16-lane rows, row / half swaps (v_permlane16_swap, v_permlane32_swap) across them.  Which of the two candidates of a level
+// comes from lane ^ OFF is read off the lane ids sent through the same instruction (no reliance on a rotation's direction).
+template <int OFF>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane)
 {
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
-        const double o = shfl_xor_f64(acc, off, lane);
-        acc = (lane & off) ? (o + acc) : (acc + o);      // lower lane's value is always the left operand
+    static_assert(OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "butterfly levels of stats_finish");
+    const unsigned id = static_cast<unsigned>(lane);
+    if constexpr (OFF == 8) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false));      // row_ror:8 == xor 8
+    } else if constexpr (OFF == 4) {
+        const unsigned a = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+        const unsigned b = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x12c, 0xf, 0xf, false));   // row_ror:12
+        const unsigned ia = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(id), 0x124, 0xf, 0xf, false));
+        return ia == (id ^ 4u) ? a : b;
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        const auto ri = __builtin_amdgcn_permlane16_swap(id, id, false, false);
+        return ri[0] == (id ^ 16u) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        const auto ri = __builtin_amdgcn_permlane32_swap(id, id, false, false);
+        return ri[0] == (id ^ 32u) ? r[0] : r[1];
     }
+}
+template <int OFF>
+__device__ __forceinline__ double xor_lane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = xor_lane_u32<OFF>(static_cast<unsigned>(b & 0xffffffffll), lane);
+    const unsigned hi = xor_lane_u32<OFF>(static_cast<unsigned>(static_cast<unsigned long long>(b) >> 32), lane);
+    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+// (it, it1 = 1 / total, 1 / (total - 1): correctly rounded divisions wherever they are made -- a kernel that finishes many signals
+//  of one shape gets them from the host instead of dividing twice per signal)
+__device__ __forceinline__ float4 stats_finish_pre(double acc, double it, double it1, int lane)
+{
+    // (butterfly over the 16 block lanes: the lower lane's value is always the left operand)
+    { const double o = xor_lane_f64<4>(acc, lane);  acc = (lane & 4) ? (o + acc) : (acc + o); }
+    { const double o = xor_lane_f64<8>(acc, lane);  acc = (lane & 8) ? (o + acc) : (acc + o); }
+    { const double o = xor_lane_f64<16>(acc, lane); acc = (lane & 16) ? (o + acc) : (acc + o); }
+    { const double o = xor_lane_f64<32>(acc, lane); acc = (lane & 32) ? (o + acc) : (acc + o); }
     auto from_lane = [&](int l) {
         const long long b = __double_as_longlong(acc);
         const int lo = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffll), l);
@@ -359,11 +394,14 @@ __device__ __forceinline__ float4 stats_finish(double acc, double total, int lan
     // (two float64 divisions -- loop-invariant for a caller that finishes many signals of one shape, as the team kernel does
     //  once per chunk -- instead of four, and the square root in float32 of the float64 variance: the result is a float32
     //  1/std either way; measured 5 % of the team kernel with four divisions and two float64 square roots)
-    const double it = 1.0 / total, it1 = 1.0 / (total - 1.0);
     const double mr = sx_re * it, mi = sx_im * it;
     const double vr = fma(-sx_re, mr, sxx_re) * it1, vi = fma(-sx_im, mi, sxx_im) * it1;
     return make_float4(static_cast<float>(mr), 1.0f / sqrtf(static_cast<float>(vr)),
                        static_cast<float>(mi), 1.0f / sqrtf(static_cast<float>(vi)));
+}
+__device__ __forceinline__ float4 stats_finish(double acc, double total, int lane)
+{
+    return stats_finish_pre(acc, 1.0 / total, 1.0 / (total - 1.0), lane);
 }
 template <class BlockSum>
 __device__ __forceinline__ float4 stats_from_blocks(int nblocks, double total, BlockSum block_sum, int lane)

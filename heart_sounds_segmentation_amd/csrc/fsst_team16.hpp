@@ -16,11 +16,14 @@
 //     features on every z-score path): 24 + the transform's ~103 = 127 of the 128 registers of four waves per SIMD (the one
 //     spill, 20 bytes, sits in front of the float64 whole-group loop of the rounding-tie path -- code object checked);
 //     the LDS regions are those of fsst_canon_kernel;
-//   * a group's statistics partial (the six float32 numbers of the two-launch path) is published as six tagged 8-byte words
-//     in the team's mailbox (relaxed agent-scope atomics: no fence, no cache write-back);
-//   * the float64 part of the statistics runs ONCE per signal and CU: the first wave of a CU that cannot go on without a
-//     signal's statistics claims it (LDS), copies the signal's partials from the mailbox, runs the very instructions of
-//     signal_stats() (fsst_kernels.hpp) on them and leaves {mean, 1/std} x 2 in LDS for its 15 siblings.
+//   * a CU takes CONSECUTIVE groups of a signal (two blocks of kStatBlock = 4), keeps their statistics partials (the six float32
+//     numbers of the two-launch path) in LDS, and the wave that delivers a block's last partial forms the block's float64 sums
+//     and publishes them as eight tagged 8-byte words in the team's mailbox (relaxed agent-scope atomics: no fence, no cache
+//     write-back);
+//   * the rest of the statistics runs ONCE per signal and CU: the first wave of a CU that cannot go on without a signal's
+//     statistics claims it (LDS), fetches the signal's <= 32 block sums from the mailbox -- two per lane, straight into the lane
+//     that adds them -- and finishes as stats_from_blocks() does (fsst_kernels.hpp: the same instructions on the same numbers as
+//     the two-launch path), leaving {mean, 1/std} x 2 in LDS for its 15 siblings.
 // What limits it (profiles/r04_team_occupancy.txt): a resolve is two trips through the memory system (the last partial
 // becoming visible, the copy) plus the sums, ~5 us against a group time of 4.5 us; with two held groups about 45 % of the
 // releases still wait.  Measured and rejected: a third held group (12 more registers: one image spills to scratch in the hot
@@ -60,11 +63,24 @@ namespace hssfsst {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
-constexpr int kT16MailWords = 6;             // tagged 8-byte words per group in the mailbox: S1re S2re S1im S2im p_re p_im
+constexpr int kT16PartFloats = 6;            // a group's statistics partial in the CU's LDS: S1re S2re S1im S2im p_re p_im
+constexpr int kT16BlockWords = 8;            // tagged 8-byte words per BLOCK of kStatBlock groups in the mailbox: the block's four
+                                             // float64 sums (sum re, sum re^2, sum im, sum im^2), each as {high, low} half
+constexpr int kT16MaxBlocks = kFusedMaxGroups / kStatBlock;      // 32 blocks per signal
+constexpr int kT16MaxCpc = 8;                // groups of a signal per CU (two blocks)
 constexpr int kT16MaxSlots = 128;            // statistics slots per CU / mailbox slots per team (signal ordinal mod slots)
-constexpr int kT16CtlFloats = 16 + 64 + 192 + 2 * kT16MaxSlots + 4 * kT16MaxSlots;
+constexpr int kT16CtlBase = 16 + 64 + 192 + 2 * kT16MaxSlots + 4 * kT16MaxSlots;
                                              // [0] ticket counter [1] dead [2] identity | column classes | wide-store offsets |
                                              // ready[slots], claim[slots] | float4 statistics[slots]
+// ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
+constexpr int t16_ctl_floats(int pslots) { return kT16CtlBase + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
+// PSLOTS for a band: what the LDS beside 16 wave regions leaves (32 signals deep where it fits, 16 for the widest band)
+template <int KLO, int KC>
+constexpr int t16_pslots()
+{
+    constexpr int room = 160 * 1024 / 4 - kCanonAtabFloats - 16 * CanonCfg<KLO, KC>::wave_floats();
+    return room >= t16_ctl_floats(32) ? 32 : room >= t16_ctl_floats(16) ? 16 : 0;
+}
 
 #ifdef HSS_T16_DEBUG
 __device__ unsigned g_t16_dbg[128];
@@ -84,7 +100,7 @@ struct Team16Params {
     const float* atab;    // f16 operand table + float64 twiddles (kCanonAtabFloats floats), then the offset table (kCanonZcFloats)
     const double* wtab;   // float64 {w, dw'}[128]                } rounding-tie path
     const double* twtab;  // float64 {cos, sin}(2 pi m / 128)     }
-    unsigned long long* mail;   // [teams][slots][ngroups][6] tagged words {tag << 32 | float32 bits}: S1re S2re S1im S2im p_re p_im
+    unsigned long long* mail;   // [teams][slots][32 blocks][8] tagged words {tag << 32 | half of a float64 block sum}
     unsigned* status;     // device status word (0 = ok)
     float r2scale_s;      // r2scale of the plan x (constant scale)^2
     float inv_c;          // 1 / constant scale
@@ -100,6 +116,7 @@ struct Team16Params {
     unsigned* abort_word; // a wait that ran out of time stores `launch` here; every wave then leaves the kernel
     unsigned* fallbacks;  // pinned host words: [0] the same store, for the host's eyes; [1] the launch that gave up because of an offset tile
     unsigned launch;      // identity of this launch (never 0)
+    double inv_total, inv_total1;   // 1 / (K ncols), 1 / (K ncols - 1): the two divisions of stats_finish, made once on the host
 };
 
 // WPB waves per block (one block per CU), DEPTH group images held per wave (registers): (16, 2) is what the library launches
@@ -122,7 +139,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     unsigned* ready = reinterpret_cast<unsigned*>(smem + ATAB + 272);        // [slots] epoch (signal ordinal + 1) of the statistics in fin[]
     unsigned* claim = ready + kT16MaxSlots;                                  // [slots] epoch some wave of this CU is resolving / has resolved
     float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * kT16MaxSlots);
-    float* wbase = smem + ATAB + kT16CtlFloats + wv * C::wave_floats();
+    constexpr int PSLOTS = t16_pslots<KLO, KC>();
+    static_assert(PSLOTS >= 16, "the CU's own partials need LDS beside the wave regions");
+    float* part_lds = smem + ATAB + kT16CtlBase;                             // [PSLOTS][kT16MaxCpc][6]
+    int* pcnt_lds = reinterpret_cast<int*>(part_lds + PSLOTS * kT16MaxCpc * kT16PartFloats);   // [PSLOTS][2] partials delivered per block
+    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS) + wv * C::wave_floats();
     u2* xrec = reinterpret_cast<u2*>(wbase);
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
     f2* disp_base = own_base + 16 * C::LD;
@@ -135,6 +156,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
     for (int i = threadIdx.x; i < 2 * kT16MaxSlots; i += 64 * WPB) ready[i] = 0u;        // ready[], claim[]
+    if (threadIdx.x < 2 * PSLOTS) pcnt_lds[threadIdx.x] = 0;
     // Block identity = ARRIVAL number ("Giving up" above)
     if (threadIdx.x == 64)
         next_q[2] = static_cast<int>(__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base);
@@ -185,10 +207,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     const int G = (ncols + 15) >> 4;
     const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     const int smask = p.slots - 1;
-    gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * G * kT16MailWords;
-    const int nwords = G * kT16MailWords;                // tagged words per signal (even: 16-byte pairs)
-    constexpr int RND = (kFusedMaxGroups * kT16MailWords + 127) / 128;     // pairs per lane
-    static_assert(RND == 6, "six 16-byte pairs per lane cover a signal's 128 x 6 words");
+    constexpr int nwords = kT16MaxBlocks * kT16BlockWords;     // tagged words per signal in the mailbox
+    gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * nwords;
+    const int nblocks = (G + kStatBlock - 1) / kStatBlock;
 
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         d_valid = false;
         while (qi < nwork) {
             ko_d = qi >> cpcs;
-            g_d = ((member + ko_d) & (T - 1)) + T * (qi & (cpc - 1));
+            g_d = (((member + ko_d) & (T - 1)) << cpcs) + (qi & (cpc - 1));       // CU c' = (member + ko) mod T: groups cpc c' ..
             if (g_d < G) { d_valid = true; break; }
             if (lane == 0) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             qi = __builtin_amdgcn_readfirstlane(qi);
@@ -254,97 +275,41 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     };
 
     // ---- Statistics of signal ordinal ko (of this team): {mean_re, 1/std_re, mean_im, 1/std_im}, once per signal and CU.
-    // The wave that has claimed the signal copies its partials from the mailbox -- lane-linear, every word fetched once, each
-    // 8-byte word validated by its own tag -- into LDS as the two-launch path's partials [G][6] and runs signal_stats() on them:
-    // the very instructions of fsst_stats_kernel on the very numbers.  The copy lives in the wave's displaced plane + flags +
-    // bitmap (contiguous, 3 088 B >= 128 groups x 24 B; all zero between groups, and zero again when the wave is done).
-    float* stage = reinterpret_cast<float*>(disp_base);
+    // The mailbox holds the signal's BLOCK sums -- float64 {sum re, sum re^2, sum im, sum im^2} of every block of kStatBlock groups,
+    // formed by the CU that transformed the block with the arithmetic of signal_stats()' inner loop (piece_moment, pieces in order)
+    // -- as tagged halves.  Lane (blk % 16, q) of the wave that has claimed the signal fetches quantity q of the blocks blk and
+    // blk + 16 (its 16-byte pairs l and l + 64: the mailbox is laid out for exactly that), adds them in that order and runs
+    // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.  A resolve used to copy all
+    // 750 partial words into LDS and do the pieces' float64 arithmetic itself, on a SIMD it shares with three transforming waves:
+    // without its sums alone the kernel ran 0.180 instead of 0.204 ms (profiles/r04_team_occupancy.txt).
 #ifdef HSS_T16_WAITS
     unsigned long long wt_copy = 0, wt_sums = 0, wt_n = 0, wt_looks = 0;
 #endif
-    // takes the valid pairs among w[] that are still needed (bit r of `need`: pair lane + 64 r) into the copy
-    auto take_pairs = [&](const ull2 (&w)[RND], unsigned tag, unsigned& need, int lane_r) {
-#pragma unroll
-        for (int r = 0; r < RND; ++r)
-            if ((need >> r) & 1u) {
-                if (static_cast<unsigned>(w[r].x >> 32) == tag && static_cast<unsigned>(w[r].y >> 32) == tag) {
-                    reinterpret_cast<f2*>(stage)[lane_r + 64 * r] = f2{__uint_as_float(static_cast<unsigned>(w[r].x)), __uint_as_float(static_cast<unsigned>(w[r].y))};
-                    need &= ~(1u << r);
-                }
-            }
-    };
-    auto pairs_needed = [&](int lane_r) -> unsigned {
-        unsigned need = 0u;
-#pragma unroll
-        for (int r = 0; r < RND; ++r) need |= (2 * (lane_r + 64 * r) < nwords ? 1u : 0u) << r;
-        return need;
-    };
-    // the copy is complete: float64 sums, result into LDS for the siblings, the copy's region zero again
-    auto finish_resolve = [&](int ko, int lane_r) {
-        wave_sync();
-        int ncols_o = ncols, K_o = K, G_o = G;
-        asm volatile("" : "+s"(ncols_o), "+s"(K_o), "+s"(G_o));
-        // signal_stats() on the copy -- its arithmetic to the letter (blocks of kStatBlock pieces summed in order, lane (blk % 16, q)
-        // over blocks blk, blk + 16, ..., stats_finish) -- with the lane's at most 2 x 4 x 3 numbers fetched from LDS up front by
-        // typed loads (through a generic pointer they were 24 dependent flat loads: most of the 1.6 us the sums took)
-        const int nblocks = (G_o + kStatBlock - 1) / kStatBlock;
-        const int q = lane_r & 3, h = q >> 1;
-        const lds_float* sp = (const lds_float*)stage;
-        float v[2][kStatBlock][3];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int pc = 0; pc < kStatBlock; ++pc) {
-                const int g = min(((lane_r >> 2) + 16 * rb) * kStatBlock + pc, G_o - 1);
-                v[rb][pc][0] = sp[g * kT16MailWords + 2 * h];
-                v[rb][pc][1] = sp[g * kT16MailWords + 2 * h + 1];
-                v[rb][pc][2] = sp[g * kT16MailWords + 4 + h];
-            }
-        double acc = 0.0;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int blk = (lane_r >> 2) + 16 * rb;
-            if (blk < nblocks) {
-                double sb = 0.0;
-#pragma unroll
-                for (int pc = 0; pc < kStatBlock; ++pc) {
-                    const int g = blk * kStatBlock + pc;
-                    if (g < G_o) {
-                        const double cnt = static_cast<double>(min(16, ncols_o - 16 * g)) * static_cast<double>(K_o);
-                        sb += piece_moment(q, static_cast<double>(v[rb][pc][0]), static_cast<double>(v[rb][pc][1]), static_cast<double>(v[rb][pc][2]), cnt);
-                    }
-                }
-                acc += sb;
-            }
-        }
-        static_assert(kFusedMaxGroups <= 2 * 16 * kStatBlock, "a lane sums at most two blocks");
-        const float4 r = stats_finish(acc, static_cast<double>(K_o) * static_cast<double>(ncols_o), lane_r);
-        wave_sync();
-        for (int i = lane_r; i < (16 * C::LDF * 2 + 4 + kCanonTieWords) / 2; i += 64) reinterpret_cast<f2*>(stage)[i] = f2{0.0f, 0.0f};
-        if (lane == 0) {
-            fin[ko & smask] = r;
-            __hip_atomic_store(ready + (ko & smask), static_cast<unsigned>(ko) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        wave_sync();
-    };
-    // the claim is this wave's: look at the mailbox until everything is there (need: what is still missing); 0 = the launch was given up
-    auto resolve_owned = [&](int ko, unsigned need, unsigned t0, int lane_r) -> int {
+    // the claim is this wave's: look at the mailbox until both of the lane's blocks are there; 0 = the launch was given up
+    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) -> int {
 #ifdef HSS_T16_WAITS
         const unsigned long long rw0 = wall_clock64();
         unsigned npolls = 0;
 #endif
+        // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
+        __builtin_amdgcn_s_setprio(3);
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
         const gu64* slot = mail + static_cast<size_t>(ko & smask) * nwords;
-        const int last = (nwords >> 1) - 1;
+        const int blk0 = lane_r >> 2;
+        unsigned need = (blk0 < nblocks ? 1u : 0u) | (blk0 + 16 < nblocks ? 2u : 0u);
+        double sb[2] = {0.0, 0.0};
         for (unsigned polls = 0;; ++polls) {
-            ull2 w[RND];
 #pragma unroll
-            for (int r = 0; r < RND; ++r) {
-                const gu64* q = slot + 2 * min(lane_r + 64 * r, last);
-                w[r].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w[r].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            take_pairs(w, tag, need, lane_r);
+            for (int rb = 0; rb < 2; ++rb)
+                if ((need >> rb) & 1u) {
+                    const gu64* q = slot + 2 * (lane_r + 64 * rb);
+                    const unsigned long long hi = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long lo = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (static_cast<unsigned>(hi >> 32) == tag && static_cast<unsigned>(lo >> 32) == tag) {
+                        sb[rb] = __longlong_as_double(static_cast<long long>((hi << 32) | (lo & 0xffffffffull)));
+                        need &= ~(1u << rb);
+                    }
+                }
 #ifdef HSS_T16_WAITS
             ++npolls;
 #endif
@@ -354,15 +319,27 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
                 const unsigned miss = __builtin_popcountll(__builtin_amdgcn_ballot_w64(need != 0u));
                 if (lane == 0 && !aborted()) __hip_atomic_store((gu32*)(P()->status), (1u << 28) | (miss << 20) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
+                __builtin_amdgcn_s_setprio(0);
                 gave_up(); return 0;
             }
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(8);
         }
         T16P(5);
 #ifdef HSS_T16_WAITS
         const unsigned long long rw1 = wall_clock64();
 #endif
-        finish_resolve(ko, lane_r);
+        // stats_from_blocks(): lane (blk % 16, q) adds its blocks blk, blk + 16 in that order, then stats_finish
+        double acc = 0.0;
+        if (blk0 < nblocks) acc += sb[0];
+        if (blk0 + 16 < nblocks) acc += sb[1];
+        static_assert(kT16MaxBlocks <= 32, "a lane sums at most two blocks");
+        const float4 r = stats_finish_pre(acc, P()->inv_total, P()->inv_total1, lane_r);
+        if (lane == 0) {
+            fin[ko & smask] = r;
+            __hip_atomic_store(ready + (ko & smask), static_cast<unsigned>(ko) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_sync();
+        __builtin_amdgcn_s_setprio(0);
 #ifdef HSS_T16_WAITS
         wt_copy += rw1 - rw0; wt_sums += wall_clock64() - rw1; wt_n += 1; wt_looks += npolls;
 #endif
@@ -384,7 +361,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         for (unsigned spins = 0;; ++spins) {
             if (stats_ready(ko)) break;
             if ((spins & 15u) == 0u && try_claim(ko)) {
-                if (resolve_owned(ko, pairs_needed(lane_r), t0, lane_r) == 0) return 0;
+                if (resolve_owned(ko, t0, lane_r) == 0) return 0;
                 break;
             }
             if ((spins & 31u) == 31u && expired(t0)) {
@@ -509,6 +486,17 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             if (lane == 0) __hip_atomic_store((gu32*)(P()->fallbacks) + 1, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the reason, for the host)
             gave_up(); return;
         }
+#ifndef HSS_T16_NO_LAGPRIO
+        {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
+            int nq = 0;
+            if (lane == 0) nq = __hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int lag = (__builtin_amdgcn_readfirstlane(nq) >> cpcs) - ko;
+#ifndef HSS_T16_LAGP
+#define HSS_T16_LAGP 0
+#endif
+            if (lag >= 2) __builtin_amdgcn_s_setprio(HSS_T16_LAGP ? 3 : 2); else if (lag == 1) __builtin_amdgcn_s_setprio(HSS_T16_LAGP ? 2 : 1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         canon_group<KLO, KC, HSS_T16_TAPB, false>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
                                            P()->x + b * P()->xstride, n, tg, P()->atab + kCanonAtabFloats);
         T16P(0);
@@ -517,18 +505,49 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         c_valid = false;
         if (d_valid) land();
         T16P(1);
-        // ---- statistics partial -> the team's mailbox: rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot
+        // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
+        //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
+        //      pieces in order, piece_moment -- and publishes them in the team's mailbox as eight tagged words
         {
             const int nvalid = min(16, cend - tg);
             f2 piv;
             const float w = canon_stats<KLO, KC>(own_base, nvalid, inv_cur, lane_o, piv);
-            const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
-            gu64* e = mail + static_cast<size_t>(ko_cur & smask) * nwords + g_cur * kT16MailWords;
+            const int pos = g_cur & (cpc - 1);           // position among the CU's groups of this signal
+            const int ps = ko_cur & (PSLOTS - 1);
+            float* pe = part_lds + (ps * kT16MaxCpc + pos) * kT16PartFloats;
             const bool odd = lane_o & 1;
             const int word = odd ? 4 + (lane_o >> 4) : (lane_o >> 4);
             const float val = odd ? ((lane_o >> 4) ? piv.y : piv.x) : w;
-            if ((lane_o & 15) == 0 || ((lane_o & 15) == 1 && lane_o < 32))
-                __hip_atomic_store(e + word, (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((lane_o & 15) == 0 || ((lane_o & 15) == 1 && lane_o < 32)) pe[word] = val;
+            wave_sync();
+            const int blk = g_cur >> 2, bfirst = blk << 2;                       // kStatBlock = 4
+            const int expect = min(kStatBlock, G - bfirst);
+            int before = 0;
+            if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(before) + 1 == expect) {
+                __builtin_amdgcn_s_setprio(3);           // (a signal's statistics wait for its last block)
+                if (lane == 0) __hip_atomic_store(pcnt_lds + 2 * ps + (pos >> 2), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wave_sync();
+                int lane_b = lane;
+                asm volatile("" : "+v"(lane_b));
+                const int q = lane_b & 3, h = q >> 1;
+                const float* pb = part_lds + (ps * kT16MaxCpc + (pos & ~3)) * kT16PartFloats;
+                double sbk = 0.0;
+                for (int pc = 0; pc < expect; ++pc) {
+                    const int gq = bfirst + pc;
+                    const double cnt = static_cast<double>(min(16, ncols - 16 * gq)) * static_cast<double>(K);
+                    sbk += piece_moment(q, static_cast<double>(pb[pc * kT16PartFloats + 2 * h]), static_cast<double>(pb[pc * kT16PartFloats + 2 * h + 1]),
+                                        static_cast<double>(pb[pc * kT16PartFloats + 4 + h]), cnt);
+                }
+                const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(sbk));
+                gu64* e = mail + static_cast<size_t>(ko_cur & smask) * nwords + (blk * 4 + q) * 2;
+                if (lane_b < 4) {
+                    __hip_atomic_store(e, (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(e + 1, (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
         draw(ko_cur);
         T16P(2);

@@ -235,7 +235,7 @@ struct hssfsst_plan {
     float* d_partials = nullptr;  size_t partials_cap = 0;   // floats (kPartFloats per statistics piece)
     unsigned* d_status = nullptr;                            // fused z-score: status word (0 = ok) as the device sees it ...
     volatile unsigned* h_status = nullptr;                   // ... and the same word in pinned host memory: read without a sync
-    unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][chunks][8] (8-byte words)
+    unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][32 blocks][8] (8-byte words)
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
     unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
@@ -536,8 +536,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     const int G = ngroups;
     if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
     // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
-    size_t lds = (kCanonAtabFloats + kT16CtlFloats + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
-    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    constexpr int PSLOTS = t16_pslots<KLO, KC>();        // signals whose partials a CU keeps in LDS at a time
+    size_t lds = (kCanonAtabFloats + t16_ctl_floats(PSLOTS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     if (lds < 84 * 1024) lds = 84 * 1024;
     auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
@@ -560,7 +560,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (T > pl->team16_cus || T > 64) return 0;
     int cpc = 1, cpc_shift = 0;                          // list positions per CU and signal (power of two; surplus ones are skipped)
     while (cpc * T < G) { cpc *= 2; ++cpc_shift; }
-    if (cpc > WPB || G / T < 1) return 0;
+    if (cpc > WPB || cpc > kT16MaxCpc || G / T < 1) return 0;
+    if (cpc < 4 && T > 1) return 0;                      // (a CU publishes whole blocks of four groups: HSSFSST_TEAM beyond G / 4)
     const int grid = (pl->team16_cus / T) * T;
     const int nteams = grid / T;
     if ((batch + nteams - 1) / nteams > 65535) return 0;
@@ -571,9 +572,10 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     int slots = 8;
     while (slots < 2 * lead + 2) slots *= 2;
     if (slots > kT16MaxSlots) return 0;
+    if (lead + 1 > PSLOTS) return 0;                     // (very short signals: more signals in flight per CU than its LDS keeps partials for)
     int rc;
     if ((rc = ensure_status(pl)) != 0) return rc;
-    const size_t words = static_cast<size_t>(nteams) * slots * G * kT16MailWords;
+    const size_t words = static_cast<size_t>(nteams) * slots * kT16MaxBlocks * kT16BlockWords;
     if (words > pl->mail_cap) {
         if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
         HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
@@ -588,6 +590,10 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     tp.mail = pl->d_mail; tp.status = pl->d_status; tp.r2scale_s = pl->canon_r2s; tp.inv_c = pl->canon_inv_c;
     tp.n = cp.n; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
     tp.team = T; tp.cpc_shift = cpc_shift; tp.slots = slots; tp.seq = pl->team_seq;
+    {   // the two float64 divisions of stats_finish (correctly rounded here as there: the same bits)
+        const double total = static_cast<double>(KC) * static_cast<double>(cp.ncols);
+        tp.inv_total = 1.0 / total; tp.inv_total1 = 1.0 / (total - 1.0);
+    }
     const unsigned spin_us = debug_switches().team_spin_us;
     tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
     if ((rc = ensure_team_words(pl, st)) != 0) return rc;

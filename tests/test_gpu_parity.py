@@ -753,7 +753,9 @@ def test_second_canonical_band(oracle_mod, n, batch):
         path, name = tf.check(), tf.last_kernel()
         if zp == "two_launch":
             assert path == 0 and name.startswith("fsst_canon_kernel<2, 24, false>"), (path, name)
-        if zp == "team" and -(-n // 16) <= 128:
+        # (this band's wave regions leave LDS for 16 signals' partials per CU: signals of a few groups, which put more signals
+        #  in flight than that, take the two-launch kernels)
+        if zp == "team" and 32 <= -(-n // 16) <= 128:
             assert name.startswith("fsst_team16_kernel<2, 24, 16, 2>"), name
         if ref is None:
             ref = got.clone()
