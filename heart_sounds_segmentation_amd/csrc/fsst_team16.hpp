@@ -488,13 +488,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         }
 #ifndef HSS_T16_NO_LAGPRIO
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
-            int nq = 0;
-            if (lane == 0) nq = __hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int lag = (__builtin_amdgcn_readfirstlane(nq) >> cpcs) - ko;
-#ifndef HSS_T16_LAGP
-#define HSS_T16_LAGP 0
-#endif
-            if (lag >= 2) __builtin_amdgcn_s_setprio(HSS_T16_LAGP ? 3 : 2); else if (lag == 1) __builtin_amdgcn_s_setprio(HSS_T16_LAGP ? 2 : 1); else __builtin_amdgcn_s_setprio(0);
+            // (what the wave's own next ticket says about the counter -- a group time old, but no trip to LDS: reading the counter
+            //  here measured the same or slower)
+            const int lag = (d_valid ? ko_d : ko + 2) - ko;
+            if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
         canon_group<KLO, KC, HSS_T16_TAPB, false>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
