@@ -184,7 +184,10 @@ int hssfsst_normalize_running(hssfsst_plan* plan, float* feats, int64_t batch, i
  *   4. out_host != NULL: copies `out` to out_host (pinned host memory) and waits for the stream: when the call
  *      returns the features of this step are on the host (the latency BASELINE config 5 asks for).
  * Requires nwin - 1 <= pos and pos + chunk <= tape_len; the caller moves the history back to the start of the
- * tape when it is full. */
+ * tape when it is full.
+ * For window lengths 256 / 512 with an even band of <= 24 rows (config 5) steps 1-4 are ONE kernel launch: x_new in device or
+ * PINNED host memory is read by the kernel where it lies (it must stay untouched until the step has run, as for the copy), a
+ * pinned, 16-byte aligned out_host is written by the kernel itself; pageable memory is copied.  Same results either way. */
 int hssfsst_stream_step(hssfsst_plan* plan, float* tape, int64_t tape_len, int64_t pos, const float* x_new,
                         int64_t x_stride, int x_on_device, int channels, int chunk, float* out, double* state,
                         float* out_host, void* stream);
