@@ -827,11 +827,8 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         int rc = 0;
         if (nt == 16 && fixed + 8 * per_wave <= room)
             rc = canon ? launch_fused_general<16, 16, 8, 3>(pl, cp, batch, ngroups, st) : launch_fused_general<16, 16, 8, -1>(pl, cp, batch, ngroups, st);
-        else if (nt == 32 && !debug_switches().no_pair) rc = 0;       // (512 points: two launches with wave pairs are faster -- 2.66 vs 3.0 ms per 1024 windows)
-        else if (nt == 32 && fixed + 8 * per_wave <= room) rc = launch_fused_general<32, 16, 8, -1>(pl, cp, batch, ngroups, st);
-        else if (nt == 32 && fixed + 6 * per_wave <= room) rc = 0;                       // (6 waves: two launches)
-        else if (nt == 32 && fixed + 4 * per_wave <= room) rc = launch_fused_general<32, 16, 4, -1>(pl, cp, batch, ngroups, st);
-        else if (nt == 32 && fixed + 3 * per_wave <= room) rc = launch_fused_general<32, 16, 3, -1>(pl, cp, batch, ngroups, st);
+        // (512 points: two launches, on wave pairs: 2.6 ms per 1024 windows against 3.0 for the single launch, whose
+        //  instantiations are gone)
         if (rc < 0) return rc;
         if (rc == 1) { *did_fuse = true; pl->last_zpath = 1; return 0; }
     }
