@@ -85,9 +85,6 @@ struct Core128Params {
     unsigned* arrive;         // [nsig] blocks of the channel that have delivered (the last one merges and normalises, and clears it)
     double* pieces;           // [nsig][groups][4] the groups' float64 sums (chunk_moments' pieces, fsst_kernels.hpp)
     float* mirror;            // the caller's pinned host buffer for the step's features (device view), or null
-    unsigned* flags;          // [nsig][groups] wait mode: the step (epoch) whose sums a group's entry of `pieces` holds
-    unsigned epoch;           // this step
-    int wait_mode;            // every wave region has ONE group and the grid is resident at once: see the kernel, "wait mode"
 };
 
 // Chunk pattern for `ngroups` 16-frame groups per signal: 8-group chunks, then 4-group chunks over the last
@@ -818,12 +815,6 @@ constexpr unsigned kSpinLimit = 1u << 18;          // polls before a wait gives 
 // a group's samples come from the tape or, from index hist on, straight from the step's new samples, which the group's wave also
 // appends to the tape (nobody reads the tape there during the step); the block that delivers last for its channel (one counter
 // per channel in HBM) runs the arithmetic of fsst_stream_finish_kernel on the channel's chunk.
-// "wait mode" of the streaming step (see the kernel): built, bit-identical, 2 us less host-visible latency and 4 % fewer steps per
-// second when steps are queued back to back (every block stays to the end of its launch, so consecutive launches no longer
-// overlap head to tail): compiled out by default.
-#ifndef HSS_STREAM_WAIT
-#define HSS_STREAM_WAIT 0
-#endif
 #ifdef HSS_STREAM_PROBE      // development (tools/stream_probe.py): 100 MHz ticks from a wave's start to its phase boundaries, kept per wave, written at the end
 constexpr int kStreamProbeWaves = 2048;
 __device__ unsigned long long g_stream_probe[kStreamProbeWaves * 8];      // [wave of the last launch][stamp]
@@ -922,13 +913,8 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
         const float* src = (p.xnew != nullptr && gi >= p.hist) ? p.xnew + ch * p.xnew_stride + (gi - p.hist) : p.x + ch * p.xstride + gi;
         return *src;
     };
-    double* s6 = reinterpret_cast<double*>(smem + ATAB + 2);      // STREAM, wait mode: the channel's running moments as they are
-                                                                  // before this step (control words 2..13)
     if constexpr (STREAM) {
         const int ch0 = static_cast<int>(blockIdx.x) / p.bpc, g0 = static_cast<int>(blockIdx.x) - ch0 * p.bpc + st_q * p.bpc;
-        // (read before this block publishes anything -- the prologue's barrier is behind it --: the one wave that writes them back
-        //  does so only after it has seen every group's flag)
-        if ((HSS_STREAM_WAIT && p.wait_mode) && threadIdx.x < 6) s6[threadIdx.x] = p.state[static_cast<long long>(ch0) * 6 + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int gi = g0 * 16 + lane + 64 * k;          // (t0 - NWIN / 2 = 16 g0: the step's frames start at col0 = NWIN / 2)
@@ -1498,9 +1484,7 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
                     // 256 CUs that all write until the last microsecond cost ~10 us of write-back after the kernel
                     if constexpr (FUSED) *reinterpret_cast<f4*>(dst4 + 64 * i) = o[i];
                     else if constexpr (STREAM) {
-                        if (p.state != nullptr && (HSS_STREAM_WAIT && p.wait_mode)) {
-                            // (wait mode: stored once, normalised, below)
-                        } else if (p.state != nullptr) {
+                        if (p.state != nullptr) {
                             // read back by the channel's last block, which may sit on another XCD: agent-scope stores (sc1, written
                             // through) and agent-scope loads there -- no L2 write-back / invalidate fences (measured: they made
                             // the step 51 us instead of 33)
@@ -1531,56 +1515,6 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
                     for (int e = 0; e < 4; ++e) {
                         const double t = wave_sum(a[e]);
                         if (lane_o == 0) __hip_atomic_store(pq + e, static_cast<unsigned long long>(__double_as_longlong(t)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if ((HSS_STREAM_WAIT && p.wait_mode)) {
-                        // ---- wait mode: the channel's groups are all in flight at once (one per wave region, the grid resident), so
-                        // this wave keeps its image in registers, tells the others that its sums are there (a flag word per group,
-                        // set to this step's number behind the sums), waits for theirs, forms the channel's moments in the order of
-                        // chunk_moments, merges them into its copy of the running moments (merge_state: every wave the same
-                        // numbers; the wave of group 0 writes them back) and stores its features ONCE, normalised.
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        unsigned* fl = p.flags + b * ngroups;
-                        if (lane_o == 0) __hip_atomic_store(fl + gidx, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bool there = false;
-                        for (unsigned spins = 0; spins < (1u << 20); ++spins) {      // (~0.1 us per look: gives up after ~0.1 s)
-                            const unsigned f = (lane_o < ngroups) ? __hip_atomic_load(fl + lane_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.epoch;
-                            if (__builtin_amdgcn_ballot_w64(f != p.epoch) == 0ull) { there = true; break; }
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                        if (!there) {
-                            if (lane_o == 0) __hip_atomic_store((gu32*)(p.status), 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        } else {
-                            const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(p.pieces + b * ngroups * 4);
-                            double m[4];
-                            moments_from_pieces(ngroups, lane_o, [&](int q, int e) {
-                                return __longlong_as_double(static_cast<long long>(__hip_atomic_load(pa + q * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-                            }, m);
-                            const bool im_blk = (lane_o & 1) != 0;       // lane 0: the real block's moments, lane 1: the imaginary block's
-                            double loc[3] = {im_blk ? s6[3] : s6[0], im_blk ? s6[4] : s6[1], im_blk ? s6[5] : s6[2]};
-                            const float2 r = merge_state(loc, im_blk ? m[2] : m[0], im_blk ? m[3] : m[1], static_cast<double>(K) * static_cast<double>(ncols));
-                            if (gidx == 0 && lane_o < 2) {
-                                double* sp = p.state + b * 6 + lane_o * 3;
-                                sp[0] = loc[0]; sp[1] = loc[1]; sp[2] = loc[2];
-                            }
-                            const float m_re = __shfl(r.x, 0, 64), i_re = __shfl(r.y, 0, 64), m_im = __shfl(r.x, 1, 64), i_im = __shfl(r.y, 1, 64);
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                if (lane_o + 64 * i < lim) {
-                                    const int c = static_cast<int>((4u * static_cast<unsigned>(lane_o + 64 * i)) % static_cast<unsigned>(C));
-                                    int c2 = c + 2;
-                                    if (c2 >= C) c2 -= C;
-                                    // ((v - mean) * (1 / std), the arithmetic of stream_normalize_apply; K is even: a pair shares its block)
-                                    f4 v = o[i];
-                                    v.x = (c < K) ? (v.x - m_re) * i_re : (v.x - m_im) * i_im;
-                                    v.y = (c < K) ? (v.y - m_re) * i_re : (v.y - m_im) * i_im;
-                                    v.z = (c2 < K) ? (v.z - m_re) * i_re : (v.z - m_im) * i_im;
-                                    v.w = (c2 < K) ? (v.w - m_re) * i_re : (v.w - m_im) * i_im;
-                                    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst4 + 64 * i));
-                                    if (p.mirror != nullptr)
-                                        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p.mirror + (b * static_cast<long long>(ncols) + tr) * C) + lane_o + 64 * i);
-                                }
-                            }
-                        }
                     }
                 }
             }
@@ -1677,7 +1611,7 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
     }
     SPROBE(1);
     if constexpr (STREAM) {
-        if (p.state != nullptr && !(HSS_STREAM_WAIT && p.wait_mode)) {
+        if (p.state != nullptr) {
             // the channel's last block to get here merges the chunk into the running moments and normalises it
             // this wave's feature stores (agent scope, written through) are out; the counter below and the loads of the last block
             // are agent-scope accesses issued after that

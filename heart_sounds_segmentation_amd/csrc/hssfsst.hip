@@ -68,7 +68,6 @@ struct DebugSwitches {
     bool split_stats = false;     // a separate statistics launch on the two-launch path
     bool no_stream_fuse = false;  // a streaming step as copy + transform + merge-and-normalise launches
     bool no_pair = false;         // nwin 256 / 512: one wave per wave region (no wave pairs)
-    bool no_stream_wait = false;  // streaming step: the channel's last block normalises (no waiting between blocks)
     int team = 0;                 // CUs per team (0: chosen by the library)
     unsigned team_spin_us = 500;  // bound of a wait inside the team kernel
     int oneplane_kb = 40;         // generic kernel: one shared LDS plane above this many KB
@@ -86,13 +85,13 @@ const DebugSwitches& debug_switches()
             else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
             else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
             else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
-            else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "no_stream_wait") d.no_stream_wait = on; else if (key == "team") d.team = iv;
+            else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "team") d.team = iv;
             else if (key == "team_spin_us") d.team_spin_us = static_cast<unsigned>(iv > 0 ? iv : 500);
             else if (key == "oneplane_kb") d.oneplane_kb = iv; else if (key == "chunks") d.chunks = iv;
             else if (key == "zgrid") d.zgrid = iv; else if (key == "zslices") d.zslices = iv;
         };
         static const char* const keys[] = {"no_fused", "no_canon", "no_team", "team_only", "team_force_fallback", "force_dft", "force_generic",
-                                           "no_mfma256", "split_stats", "no_stream_fuse", "no_pair", "no_stream_wait", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
+                                           "no_mfma256", "split_stats", "no_stream_fuse", "no_pair", "team", "team_spin_us", "oneplane_kb", "chunks", "zgrid", "zslices"};
         for (const char* k : keys) {                       // HSSFSST_<KEY>
             std::string name = "HSSFSST_";
             for (const char* c = k; *c; ++c) name += static_cast<char>(std::toupper(static_cast<unsigned char>(*c)));
@@ -252,7 +251,6 @@ struct hssfsst_plan {
     int stream_slots = 0;                     // the same for the streaming-step kernel
     unsigned* d_stream_arrive = nullptr; int stream_arrive_cap = 0;   // streaming step: blocks delivered per channel
     double* d_stream_pieces = nullptr; long long stream_pieces_cap = 0;   // and the groups' float64 sums [channels][groups][4]
-    unsigned* d_stream_flags = nullptr; unsigned stream_epoch = 0;        // ... with the step they belong to (wait mode)
     int fused_slots = 0;                      // CUs usable by the fused kernel (0 = not queried yet, -1 = none)
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
@@ -387,10 +385,7 @@ int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const fl
     }
     if (state && pl->stream_pieces_cap < static_cast<long long>(channels) * ngroups) {
         if (pl->d_stream_pieces) { HIP_TRY(hipFree(pl->d_stream_pieces)); pl->d_stream_pieces = nullptr; pl->stream_pieces_cap = 0; }
-        if (pl->d_stream_flags) { HIP_TRY(hipFree(pl->d_stream_flags)); pl->d_stream_flags = nullptr; }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_pieces), static_cast<size_t>(channels) * ngroups * 4 * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_stream_flags), static_cast<size_t>(channels) * ngroups * sizeof(unsigned)));
-        HIP_TRY(hipMemsetAsync(pl->d_stream_flags, 0, static_cast<size_t>(channels) * ngroups * sizeof(unsigned), st));
         pl->stream_pieces_cap = static_cast<long long>(channels) * ngroups;
     }
     if (int rcs = ensure_status(pl)) return rcs;
@@ -404,13 +399,8 @@ int launch_stream(hssfsst_plan* pl, float* tape_at, long long tape_len, const fl
     cp.col0 = pl->nwin / 2; cp.ncols = chunk; cp.reg = reg;
     cp.xnew = x_new_dev; cp.xnew_stride = x_stride; cp.hist = pl->nwin - 1; cp.bpc = bpc; cp.state = state; cp.arrive = pl->d_stream_arrive; cp.pieces = pl->d_stream_pieces; cp.mirror = mirror;
     const long long grid = static_cast<long long>(channels) * bpc;
-    // wait mode (fsst_mfma128.hpp): every group of a channel in flight at once and the whole grid resident -- the features are
-    // written once, normalised; otherwise the channel's last block reads them back
-    constexpr int kRegions = PAIR ? WPB / 2 : WPB;
     cp.status = pl->d_status;
-    cp.flags = pl->d_stream_flags; cp.epoch = ++pl->stream_epoch;
-    cp.wait_mode = (HSS_STREAM_WAIT && state != nullptr && ngroups <= bpc * kRegions && ngroups <= 64 && grid <= pl->stream_slots && !debug_switches().no_stream_wait) ? 1 : 0;
-    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "", cp.wait_mode ? ", wait" : "");
+    name_kernel(pl, WPB, grid, "fsst_core128_kernel<%d, %d, %d, true, %d, -1, false, stream%s>", NT, RQ, kFpw128, WPB, PAIR ? ", pairs" : "");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -1234,7 +1224,6 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_atab16) (void)hipFree(p->d_atab16);
     if (p->d_stream_arrive) (void)hipFree(p->d_stream_arrive);
     if (p->d_stream_pieces) (void)hipFree(p->d_stream_pieces);
-    if (p->d_stream_flags) (void)hipFree(p->d_stream_flags);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
