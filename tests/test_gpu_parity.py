@@ -957,8 +957,9 @@ def test_bench_c3_config_line():
 
 def _expected_zscore_path(n, batch):
     """hssfsst_plan_last_exec_fused for the canonical configuration (hssfsst.hip launch_core128): the team kernel wherever it
-    applies -- signals of at most 128 groups of 16 frames --, two launches beyond."""
-    return 2 if -(-n // 16) <= 128 else 0
+    applies -- signals of 3 .. 128 groups of 16 frames (one or two groups per signal put more signals in flight per CU than its
+    LDS keeps partials for) --, two launches otherwise."""
+    return 2 if 3 <= -(-n // 16) <= 128 else 0
 
 
 _ZS_CHILD = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
