@@ -970,7 +970,7 @@ _ZS_CHILD = ("import sys, numpy as np, torch; sys.path.insert(0, %r); "
 
 
 @pytest.mark.parametrize("n,batch", [(2000, 1024), (2000, 517), (1999, 256), (1000, 300), (250, 512), (961, 512), (2048, 256), (33, 1024),
-                                     (2000, 50), (2000, 1), (2000, 1100), (4096, 5), (4100, 3), (64, 3), (130, 700)])
+                                     (2000, 50), (2000, 1), (2000, 1100), (4096, 5), (4100, 3), (64, 3), (130, 700), (20, 300), (48, 40)])
 def test_fused_zscore_bit_identical_to_two_kernel_path(n, batch):
     """The two single-launch z-score kernels -- one CU per signal with the statistics resolved in LDS (full batches),
     teams of CUs with the features held in registers and float64 block sums exchanged through mailboxes (everything
