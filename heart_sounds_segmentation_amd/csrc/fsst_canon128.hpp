@@ -126,15 +126,13 @@ constexpr float kOffsetErr2 = HSS_OFFERR;                   // (5e-7 / 2e-6)^2: 
 template <bool OFFS = true>
 __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec, float r2scale_s, float inv_c, int lane, int t0, int n)
 {
-    float e2 = 0.0f, s1 = 0.0f, cnt = 0.0f;
-    bool in[3];
+    // (samples outside the signal are zeros in sreg: canon_fetch; how many of the tile's 192 slots lie inside it is wave-uniform
+    //  arithmetic -- the per-lane count that used to ride through the reduction cost 12 instructions per tile)
+    float e2 = 0.0f, s1 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int gi = t0 + lane + 64 * k - 64;
-        in[k] = (gi >= 0 && gi < n);
-        e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; cnt += in[k] ? 1.0f : 0.0f;
-    }
-    const TileEnergy te = tile_energy(e2, s1, cnt);
+    for (int k = 0; k < 3; ++k) { e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; }
+    const int inside = min(t0 + 128, n) - max(t0 - 64, 0);
+    const TileEnergy te = tile_energy(e2, s1, static_cast<float>(max(inside, 0)));
     float E = te.E, mean = 0.0f, Edc = 0.0f;
     float x[3] = {sreg[0], sreg[1], sreg[2]};
     if (__builtin_expect(te.E > 0.0f && te.S1 * te.S1 >= kMeanTheta * te.C * te.E, 0)) {
@@ -142,7 +140,11 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
         mean = te.S1 / te.C;
         float ea = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { x[k] = in[k] ? sreg[k] - mean : 0.0f; ea = fmaf(x[k], x[k], ea); }
+        for (int k = 0; k < 3; ++k) {
+            const int gi = t0 + lane + 64 * k - 64;
+            x[k] = (gi >= 0 && gi < n) ? sreg[k] - mean : 0.0f;
+            ea = fmaf(x[k], x[k], ea);
+        }
         E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(ea, 0.0f, 0.0f, 0.0f))));     // (recomputed: E - S1^2 / n cancels)
         Edc = te.S1 * mean;
     }
@@ -484,14 +486,16 @@ struct CanonParams {
 constexpr int kCanonCtlFloats = 16 + 192;                            // [0] work counter, [16..207] wide-store offsets
 constexpr int kCanonCtlFusedFloats = kCtlFusedFloats;                // the layout of fsst_core128_kernel<FUSED>
 
-// The three samples per lane of the aligned tile that starts at output column t0 (xpad index t0 + i <-> sample t0 + i - 64).
+// The three samples per lane of the aligned tile that starts at output column t0 (xpad index t0 + i <-> sample t0 + i - 64),
+// zero outside the signal.  Buffer loads: the signal is a raw buffer of n floats, an offset outside it (negative ones are huge
+// as unsigned) returns 0 -- the zero padding of oracle/fsst_oracle.c step 1 done by the address unit, no compare / exec-mask /
+// 64-bit address per sample.
 __device__ __forceinline__ void canon_fetch(const float* xsig, int n, int t0, int lane_o, float (&sreg)[3])
 {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsig), 0, n * 4, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int gi = t0 + lane_o + 64 * k - 64;
-        sreg[k] = (gi >= 0 && gi < n) ? xsig[gi] : 0.0f;
-    }
+    for (int k = 0; k < 3; ++k)
+        sreg[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (t0 + lane_o + 64 * k - 64) * 4, 0, 0));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -24,9 +24,9 @@ def main():
     assert rc == 0, L.hssfsst_last_error()
     X = torch.from_numpy(synth.pcg_windows(B, n)).cuda()
     out = torch.empty((B, n, 44), dtype=torch.float32, device="cuda")
-    for rd in range(4):
+    for rd in range(int(os.environ.get("T16_ROUNDS", "4"))):
         L.hssfsst_plan_set_timing(plan, 1)
-        for _ in range(100):
+        for _ in range(int(os.environ.get("T16_EXECS", "100"))):
             rc = L.hssfsst_exec(plan, ctypes.c_void_p(X.data_ptr()), B, n, 1, ctypes.c_void_p(out.data_ptr()), 1, None)
             assert rc == 0, L.hssfsst_last_error()
         ms = (ctypes.c_float * 2)(); cnt = ctypes.c_int()
