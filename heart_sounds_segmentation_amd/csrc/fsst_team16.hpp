@@ -68,10 +68,12 @@ constexpr int kT16BlockWords = 8;            // tagged 8-byte words per BLOCK of
                                              // float64 sums (sum re, sum re^2, sum im, sum im^2), each as {high, low} half
 constexpr int kT16MaxBlocks = kFusedMaxGroups / kStatBlock;      // 32 blocks per signal
 constexpr int kT16MaxCpc = 8;                // groups of a signal per CU (two blocks)
-constexpr int kT16MaxSlots = 128;            // statistics slots per CU / mailbox slots per team (signal ordinal mod slots)
-constexpr int kT16CtlBase = 16 + 64 + 192 + 2 * kT16MaxSlots + 4 * kT16MaxSlots;
-                                             // [0] ticket counter [1] dead [2] identity | column classes | wide-store offsets |
-                                             // ready[slots], claim[slots] | float4 statistics[slots]
+constexpr int kT16MaxSlots = 64;             // statistics slots per CU / mailbox slots per team (signal ordinal mod slots)
+constexpr int kT16StatFloats = 12;           // a signal's statistics in LDS: three float4 {mean, 1/std} pairs -- (re, re), (re, im), (im, im): the
+                                             // z-score of a float4 of the image reads the one its two column pairs need (emit_held)
+constexpr int kT16CtlBase = 16 + 64 + 192 + 2 * kT16MaxSlots + kT16StatFloats * kT16MaxSlots;
+                                             // [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets |
+                                             // ready[slots], claim[slots] | statistics[slots][3] float4
 // ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
 constexpr int t16_ctl_floats(int pslots) { return kT16CtlBase + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
 // PSLOTS for a band: what the LDS beside 16 wave regions leaves (32 signals deep where it fits, 16 for the widest band)
@@ -81,18 +83,6 @@ constexpr int t16_pslots()
     constexpr int room = 160 * 1024 / 4 - kCanonAtabFloats - 16 * CanonCfg<KLO, KC>::wave_floats();
     return room >= t16_ctl_floats(32) ? 32 : room >= t16_ctl_floats(16) ? 16 : 0;
 }
-
-#ifdef HSS_T16_DEBUG
-__device__ unsigned g_t16_dbg[128];
-#endif
-#if defined(HSS_T16_PROBE) || defined(HSS_T16_WAITS)
-__device__ unsigned long long g_t16_probe[16];
-#endif
-#ifdef HSS_T16_PROBE     // development: shader-clock totals per phase over all waves (results valid, kernel slowed by the stamps)
-#define T16P(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); pr_t[k] += now_ - pr_last; pr_last = now_; } while (0)
-#else
-#define T16P(k) do { } while (0)
-#endif
 
 struct Team16Params {
     const float* x;       // [nsig][xstride]
@@ -124,21 +114,20 @@ template <int KLO, int KC, int WPB, int DEPTH>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Params p)
 {
     using C = CanonCfg<KLO, KC>;
-    static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 4, "whole waves per SIMD; a ring of at most four held groups");
+    static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 4, "whole waves per SIMD; at most four held groups");
     constexpr int K = KC, ATAB = kCanonAtabFloats;
-    using ull2 = unsigned long long __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = p.n;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* atab = smem;
-    int* next_q = reinterpret_cast<int*>(smem + ATAB);
+    int* next_q = reinterpret_cast<int*>(smem + ATAB);                       // [0] ticket counter [1] dead [2] identity
     unsigned* dead = reinterpret_cast<unsigned*>(smem + ATAB) + 1;
-    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64]
+    unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64] byte i: which of a signal's three float4 statistics float4 lane + 64 i reads
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // [3][64]
     unsigned* ready = reinterpret_cast<unsigned*>(smem + ATAB + 272);        // [slots] epoch (signal ordinal + 1) of the statistics in fin[]
     unsigned* claim = ready + kT16MaxSlots;                                  // [slots] epoch some wave of this CU is resolving / has resolved
-    float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * kT16MaxSlots);
+    float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * kT16MaxSlots);      // [slots][3]
     constexpr int PSLOTS = t16_pslots<KLO, KC>();
     static_assert(PSLOTS >= 16, "the CU's own partials need LDS beside the wave regions");
     float* part_lds = smem + ATAB + kT16CtlBase;                             // [PSLOTS][kT16MaxCpc][6]
@@ -161,18 +150,19 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     if (threadIdx.x == 64)
         next_q[2] = static_cast<int>(__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base);
     if (wv == 0) {
-        unsigned cls = 0u;                               // bit 2i / 2i+1: the first / second pair of float4 i is imaginary
+        unsigned cofs = 0u;                              // byte i: 16 x (number of imaginary column pairs of float4 lane + 64 i)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const unsigned c = (4u * static_cast<unsigned>(lane + 64 * i)) % static_cast<unsigned>(2 * K);
-            cls |= (c >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i);
-            cls |= (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u) << (2 * i + 1);
+            const unsigned nim = (c >= static_cast<unsigned>(K) ? 1u : 0u) + (c + 2 >= static_cast<unsigned>(K) ? 1u : 0u);
+            cofs |= (16u * nim) << (8 * i);
             ppk_lds[i * 64 + lane] = canon_store_offsets<KLO, KC>(lane + 64 * i);
         }
-        cls_lds[lane] = cls;
+        cls_lds[lane] = cofs;
     }
     __syncthreads();
 
+    // cold parameters are re-read from the kernel arguments where they are used (rare paths), the hot ones stay in scalar registers
     using kparams = const __attribute__((address_space(4))) Team16Params;
     kparams* const kp_ = (kparams*)__builtin_amdgcn_kernarg_segment_ptr();
     auto P = [&]() -> kparams* { kparams* q = kp_; asm volatile("" : "+s"(q)); return q; };
@@ -210,30 +200,33 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     constexpr int nwords = kT16MaxBlocks * kT16BlockWords;     // tagged words per signal in the mailbox
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * nwords;
     const int nblocks = (G + kStatBlock - 1) / kStatBlock;
+    const long long sig_bytes = static_cast<long long>(ncols) * (2 * K * 4);      // a signal's feature block
 
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
-#ifdef HSS_T16_PROBE
-    unsigned long long pr_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pr_last = __builtin_readcyclecounter();
-    const unsigned long long pr_begin = pr_last;
-#endif
 
     // ---- draw: the next group of this CU's list and its tile's samples on their way into registers
     float sreg[3];
-    bool d_valid = false;
-    int ko_d = 0, g_d = 0;
+    bool d_valid = false, saw_dead = false;
+    int ko_d = 0, g_d = 0, q_last = -1;                  // (q_last: the last ticket this wave drew)
     // after_ko >= 0: draw only if every position still to be handed out belongs to a signal AFTER after_ko (see "Progress":
-    // a ticket the wave holds unpublished while it waits must not belong to the signal it waits for)
+    // a ticket the wave holds unpublished while it waits must not belong to the signal it waits for).  The counter only grows and
+    // stands behind this wave's last ticket: when the position after that one already lies in a later signal there is nothing to
+    // look at (one LDS round trip instead of two).  The block's `dead` word rides along with the ticket.
     auto draw = [&](int after_ko) {
         int qi = 0x7fffffff;
+        unsigned dd = 0u;
+        const bool known = after_ko < 0 || ((q_last + 1) >> cpcs) > after_ko;
         if (lane == 0) {
-            const bool go = after_ko < 0 || (__hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> cpcs) > after_ko;
+            const bool go = known || (__hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> cpcs) > after_ko;
             if (go) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            dd = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
+        saw_dead = __builtin_amdgcn_readfirstlane(dd) != 0u;
         d_valid = false;
         while (qi < nwork) {
+            q_last = qi;
             ko_d = qi >> cpcs;
             g_d = (((member + ko_d) & (T - 1)) << cpcs) + (qi & (cpc - 1));       // CU c' = (member + ko) mod T: groups cpc c' ..
             if (g_d < G) { d_valid = true; break; }
@@ -248,24 +241,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         }
     };
 
-    // ---- the held groups: images in registers (feature units, un-normalised), waiting for their signals' statistics
-    // (a ring: slot (h_head + i) % DEPTH holds the i-th oldest, i < h_cnt; slot indices are wave-uniform, so every access is a
-    //  branch around code that names its own registers -- no indexed moves)
-    int h_head = 0, h_cnt = 0;
-    int ko_hs[DEPTH], g_hs[DEPTH];
-    f4 held[DEPTH][3];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { ko_hs[d] = 0; g_hs[d] = 0; }
-
     auto stats_ready = [&](int ko) -> bool {             // the CU already has this signal's statistics
         unsigned have = 0u;
         if (lane == 0) have = __hip_atomic_load(ready + (ko & smask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(have)) == static_cast<unsigned>(ko) + 1u;
-    };
-    auto stats_claimed = [&](int ko) -> bool {           // ... or one of its waves is getting them
-        unsigned c = 0u;
-        if (lane == 0) c = __hip_atomic_load(claim + (ko & smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(c)) >= static_cast<unsigned>(ko) + 1u;
     };
     auto try_claim = [&](int ko) -> bool {
         unsigned mine = 0u;
@@ -279,18 +258,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     // formed by the CU that transformed the block with the arithmetic of signal_stats()' inner loop (piece_moment, pieces in order)
     // -- as tagged halves.  Lane (blk % 16, q) of the wave that has claimed the signal fetches quantity q of the blocks blk and
     // blk + 16 (its 16-byte pairs l and l + 64: the mailbox is laid out for exactly that), adds them in that order and runs
-    // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.  A resolve used to copy all
-    // 750 partial words into LDS and do the pieces' float64 arithmetic itself, on a SIMD it shares with three transforming waves:
-    // without its sums alone the kernel ran 0.180 instead of 0.204 ms (profiles/r04_team_occupancy.txt).
-#ifdef HSS_T16_WAITS
-    unsigned long long wt_copy = 0, wt_sums = 0, wt_n = 0, wt_looks = 0;
-#endif
+    // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.
     // the claim is this wave's: look at the mailbox until both of the lane's blocks are there; 0 = the launch was given up
     auto resolve_owned = [&](int ko, unsigned t0, int lane_r) -> int {
-#ifdef HSS_T16_WAITS
-        const unsigned long long rw0 = wall_clock64();
-        unsigned npolls = 0;
-#endif
         // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
         __builtin_amdgcn_s_setprio(3);
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
@@ -310,24 +280,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
                         need &= ~(1u << rb);
                     }
                 }
-#ifdef HSS_T16_WAITS
-            ++npolls;
-#endif
             if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
             if ((polls & 7u) == 7u && expired(t0)) {
-#ifdef HSS_T16_DEBUG
-                const unsigned miss = __builtin_popcountll(__builtin_amdgcn_ballot_w64(need != 0u));
-                if (lane == 0 && !aborted()) __hip_atomic_store((gu32*)(P()->status), (1u << 28) | (miss << 20) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
                 __builtin_amdgcn_s_setprio(0);
                 gave_up(); return 0;
             }
             __builtin_amdgcn_s_sleep(8);
         }
-        T16P(5);
-#ifdef HSS_T16_WAITS
-        const unsigned long long rw1 = wall_clock64();
-#endif
         // stats_from_blocks(): lane (blk % 16, q) adds its blocks blk, blk + 16 in that order, then stats_finish
         double acc = 0.0;
         if (blk0 < nblocks) acc += sb[0];
@@ -335,56 +294,44 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         static_assert(kT16MaxBlocks <= 32, "a lane sums at most two blocks");
         const float4 r = stats_finish_pre(acc, P()->inv_total, P()->inv_total1, lane_r);
         if (lane == 0) {
-            fin[ko & smask] = r;
+            float4* f3 = fin + 3 * (ko & smask);
+            f3[0] = make_float4(r.x, r.y, r.x, r.y);
+            f3[1] = make_float4(r.x, r.y, r.z, r.w);
+            f3[2] = make_float4(r.z, r.w, r.z, r.w);
             __hip_atomic_store(ready + (ko & smask), static_cast<unsigned>(ko) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         wave_sync();
         __builtin_amdgcn_s_setprio(0);
-#ifdef HSS_T16_WAITS
-        wt_copy += rw1 - rw0; wt_sums += wall_clock64() - rw1; wt_n += 1; wt_looks += npolls;
-#endif
-        T16P(6);
-#ifdef HSS_T16_PROBE
-        pr_t[9] += 1;
-#endif
         return 1;
     };
-    // the statistics for a wave that cannot go on without them: a sibling's result, or this wave resolves; 0 = the launch was given up
-    auto signal_statistics = [&](int ko, float4& st) -> int {
+    // a wave cannot go on without a signal's statistics: a sibling's result, or this wave resolves; 0 = the launch was given up
+    auto signal_statistics = [&](int ko) -> int {
 #if defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2)      // development: nobody waits, nobody resolves (results invalid)
-        st = make_float4(0.0f, 1.0f, 0.0f, 1.0f);
         return 1;
 #endif
+        if (stats_ready(ko)) return 1;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned t0 = static_cast<unsigned>(wall_clock64());
         for (unsigned spins = 0;; ++spins) {
-            if (stats_ready(ko)) break;
-            if ((spins & 15u) == 0u && try_claim(ko)) {
-                if (resolve_owned(ko, t0, lane_r) == 0) return 0;
-                break;
-            }
-            if ((spins & 31u) == 31u && expired(t0)) {
-#ifdef HSS_T16_DEBUG
-                if (lane == 0 && !aborted() && !is_dead()) __hip_atomic_store((gu32*)(P()->status), (2u << 28) | ((unsigned)member << 16) | (static_cast<unsigned>(ko) & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
-                gave_up(); return 0;
-            }
+            if ((spins & 15u) == 0u && try_claim(ko)) return resolve_owned(ko, t0, lane_r);
+            if ((spins & 31u) == 31u && expired(t0)) { gave_up(); return 0; }
             if (is_dead()) return 0;
             __builtin_amdgcn_s_sleep(4);
+            if (stats_ready(ko)) return 1;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        st = fin[ko & smask];
-        T16P(4);
-        return 1;
     };
 
     // z-score of a held group from registers -- (v - mean) * (1 / std), two roundings, exactly as fsst_normalize_kernel -- and
-    // its 3 streaming stores per lane
-    auto emit_held = [&](const f4 (&hv)[3], int ko_h, int g_h, const float4& st) {
+    // its 3 streaming stores per lane.  {mean, 1 / std} of a float4's two column pairs come as ONE 16-byte LDS read: the signal's
+    // statistics lie there three times -- (re, re), (re, im), (im, im) -- and which one float4 lane + 64 i needs is a constant of
+    // the lane (cls_lds): no per-element selects.  The store address is scalar base + lane offset.
+    auto emit_held = [&](const f4 (&hv)[3], int ko_h, int g_h) {
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
-        const unsigned cls = cls_lds[lane_r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned cofs = cls_lds[lane_r];
+        const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_h & smask));
         auto zs = [](f2 v, f2 m) -> f2 {
             f2 d, e;
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(m));
@@ -392,17 +339,17 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             return e;
         };
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko_h) * nteams;
-        float4* d4 = reinterpret_cast<float4*>(P()->out + (b * static_cast<long long>(ncols) + g_h * 16) * (2 * K)) + lane_r;
+        char* obase = reinterpret_cast<char*>(P()->out) + b * sig_bytes + static_cast<long long>(g_h) * (16 * 2 * K * 4);       // (wave-uniform)
+        const unsigned voff = static_cast<unsigned>(lane_r) * 16u;
         const int nvalid = min(16, ncols - g_h * 16);
         auto put = [&](int i) {
-            const bool im0 = (cls >> (2 * i)) & 1u, im1 = (cls >> (2 * i + 1)) & 1u;
-            const f2 m0 = f2{im0 ? st.z : st.x, im0 ? st.w : st.y}, m1 = f2{im1 ? st.z : st.x, im1 ? st.w : st.y};
-            const f2 lo = zs(f2{hv[i].x, hv[i].y}, m0);
-            const f2 hi = zs(f2{hv[i].z, hv[i].w}, m1);
+            const float4 tt = *reinterpret_cast<const float4*>(tb + ((cofs >> (8 * i)) & 0xffu));
+            const f2 lo = zs(f2{hv[i].x, hv[i].y}, f2{tt.x, tt.y});
+            const f2 hi = zs(f2{hv[i].z, hv[i].w}, f2{tt.z, tt.w});
 #if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 2      // development: the arithmetic without the stores
             { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
 #else
-            __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(d4 + 64 * i));
+            __builtin_nontemporal_store(f4{lo.x, lo.y, hi.x, hi.y}, reinterpret_cast<f4*>(obase + (voff + 1024u * static_cast<unsigned>(i))));
 #endif
         };
         if (__builtin_expect(nvalid == 16, 1)) {
@@ -420,43 +367,26 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         }
     };
 
-    // held groups leave, oldest first: every one whose signal's statistics the CU already has; the oldest is WAITED for only
-    // when the ring is full (all = true: until the ring is empty -- end of the list); false = the launch was given up
-    auto release = [&](bool all) -> bool {
-        while (h_cnt > 0) {
-            int ko_o = 0;
-            static_for<DEPTH>([&](auto S) { if (h_head == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
-            float4 st;
-            if (stats_ready(ko_o)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                st = fin[ko_o & smask];
-            } else {
-                if (!(all || h_cnt == DEPTH)) break;
-                if (signal_statistics(ko_o, st) == 0) return false;
-            }
-            static_for<DEPTH>([&](auto S) {
-                constexpr int sl = decltype(S)::value;
-                if (h_head == sl) emit_held(held[sl], ko_hs[sl], g_hs[sl], st);
-            });
-            h_head = (h_head + 1) % DEPTH;
-            --h_cnt;
-            T16P(3);
-        }
-        return true;
-    };
+    // ---- the held groups: images in registers (feature units, un-normalised), waiting for their signals' statistics.  A strict
+    // first-in first-out of DEPTH slots, the main loop unrolled DEPTH times: step s fills slot s, after the group that sat there
+    // -- the oldest the wave holds -- has left.  (A ring with early releases, whose slots were picked at run time, cost a dozen
+    // register moves per group at the loop head and a page of scalar bookkeeping; nothing is gained by a group leaving early.)
+    int nheld = 0;
+    int ko_hs[DEPTH], g_hs[DEPTH];
+    f4 held[DEPTH][3];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { ko_hs[d] = 0; g_hs[d] = 0; }
 
-    // One loop body, in this order -- a wave's memory operations retire in order, so the ONE wait for loaded data per group
-    // (the next tile's samples) sits where everything else in flight -- the
-    // previous group's stores -- is a whole transform old:
+    // One step, in this order -- a wave's memory operations retire in order, so the ONE wait for loaded data per group (the next
+    // tile's samples) sits where everything else in flight -- the previous group's stores -- is a whole transform old:
     //   1. transform the landed group;
     //   2. land the drawn group's tile (its records are free: every group stages its own tile);
-    //   3. statistics partial of the transformed group -> mailbox; draw a further group and request its samples -- IF that is
-    //      safe: a ticket the wave holds unpublished across its waits must belong to a later signal than any it may wait for
-    //      (the ticket counter is looked at first; positions only grow).  Otherwise the wave draws when it has nothing landed
-    //      -- holding only published groups (rare: the slow path at the top);
-    //   4. held groups whose statistics are there leave (z-score from registers, 3 stores each); the oldest is WAITED for only
-    //      when the ring is full;
-    //   5. the transformed group's image: own plane -> the ring's free slot.
+    //   3. statistics partial of the transformed group -> LDS, a block's last partial -> mailbox; draw a further group and request
+    //      its samples -- IF that is safe: a ticket the wave holds unpublished across its waits must belong to a later signal than
+    //      any it may wait for.  Otherwise the wave draws when it has nothing landed -- holding only published groups (rare: the
+    //      slow path at the top);
+    //   4. the group in this step's slot leaves: its signal's statistics are waited for, z-score from registers, 3 stores;
+    //   5. the transformed group's image: own plane -> the slot.
     bool c_valid = false;                                // a group is landed: (ko, g), its tile in xrec
     int ko = 0, g = 0;
     CanonTile tile{};
@@ -466,16 +396,15 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         tile = canon_land<false>(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t, ((g_d + cg0) & ~3) * 16, n);
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
-    draw(-1);
-    if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
-    for (;;) {
-        if (is_dead()) return;                           // the launch was given up (a wave that waits also looks at the abort word)
+    // 0: go on, 1: the list is done, 2: the launch was given up
+    int slot = 0;                                        // the slot this step fills (steps take the slots in turn)
+    auto step = [&]() -> int {
         if (!c_valid) {                                  // slow path: nothing landed -- the wave holds nothing unpublished
             if (!d_valid) draw(-1);
-            if (!d_valid) break;
+            if (saw_dead) return 2;
+            if (!d_valid) return 1;
             land();
         }
-        T16P(8);
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
@@ -484,24 +413,21 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         //  exec goes to the kernels queued behind it, which have it -- same bits as on every path)
         if (__builtin_expect(tile.mean_s != tile.mean_s, 0)) {
             if (lane == 0) __hip_atomic_store((gu32*)(P()->fallbacks) + 1, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the reason, for the host)
-            gave_up(); return;
+            gave_up(); return 2;
         }
 #ifndef HSS_T16_NO_LAGPRIO
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
-            // (what the wave's own next ticket says about the counter -- a group time old, but no trip to LDS: reading the counter
-            //  here measured the same or slower)
+            // (what the wave's own next ticket says about the counter -- a group time old, but no trip to LDS)
             const int lag = (d_valid ? ko_d : ko + 2) - ko;
             if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
         canon_group<KLO, KC, HSS_T16_TAPB, false>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
                                            P()->x + b * P()->xstride, n, tg, P()->atab + kCanonAtabFloats);
-        T16P(0);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
         c_valid = false;
         if (d_valid) land();
-        T16P(1);
         // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
         //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
         //      pieces in order, piece_moment -- and publishes them in the team's mailbox as eight tagged words
@@ -547,35 +473,44 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             }
         }
         draw(ko_cur);
-        T16P(2);
-        if (!release(false)) return;
-        // ---- the new group's image: own plane -> the ring's free slot (feature units)
-        {
-            const int tail = (h_head + h_cnt) % DEPTH;
-            static_for<DEPTH>([&](auto S) {
-                constexpr int sl = decltype(S)::value;
-                if (tail == sl) { canon_image<KLO, KC>(own_base, ppk_lds, inv_cur, lane_o, held[sl]); ko_hs[sl] = ko_cur; g_hs[sl] = g_cur; }
-            });
-            ++h_cnt;
-        }
+        if (saw_dead) return 2;
+        // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in
+        int ko_o = 0;
+        static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
+        const bool full = nheld == DEPTH;
+        if (full) { if (signal_statistics(ko_o) == 0) return 2; }
+        else ++nheld;
+        static_for<DEPTH>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            if (slot == sl) {
+                if (full) emit_held(held[sl], ko_hs[sl], g_hs[sl]);
+                canon_image<KLO, KC>(own_base, ppk_lds, inv_cur, lane_o, held[sl]);
+                ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
+            }
+        });
+        slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
         wave_sync();
-        T16P(7);
-#ifdef HSS_T16_PROBE
-        pr_t[10] += 1;
-#endif
+        return 0;
+    };
+    draw(-1);
+    if (saw_dead) return;
+    if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
+    int rc = 0;
+    do { rc = step(); } while (rc == 0);
+    if (rc == 2) return;
+    // ---- the list is done: the held groups leave, oldest first
+    for (int i = 0; i < nheld; ++i) {
+        const int so = (slot + DEPTH - nheld + i) % DEPTH;
+        bool ok = true;
+        static_for<DEPTH>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            if (so == sl) {
+                if (signal_statistics(ko_hs[sl]) == 0) ok = false;
+                else emit_held(held[sl], ko_hs[sl], g_hs[sl]);
+            }
+        });
+        if (!ok) return;
     }
-    if (!release(true)) return;
-#ifdef HSS_T16_WAITS
-    if (lane == 0 && wt_n) { atomicAdd(g_t16_probe + 4, wt_copy); atomicAdd(g_t16_probe + 5, wt_sums); atomicAdd(g_t16_probe + 6, wt_n); atomicAdd(g_t16_probe + 7, wt_looks); }
-#endif
-#ifdef HSS_T16_PROBE
-    // [0] transform [1] land [2] stats + publish + draw [3] emit [4] wait (waiter, incl. resolver total) [5] resolver: poll [6] resolver: compute [7] image [8] loop top
-    if (lane == 0) {
-        pr_t[11] = __builtin_readcyclecounter() - pr_begin;
-        for (int k = 0; k < 12; ++k) atomicAdd(g_t16_probe + k, pr_t[k]);
-        atomicAdd(g_t16_probe + 12, 1ull);
-    }
-#endif
 }
 
 }  // namespace hssfsst
