@@ -178,6 +178,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         }
     };
     auto is_dead = [&]() -> bool { return __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; };
+    // A wave that finds the launch given up ENDS where it stands (s_endpgm from inline assembly: no control-flow edge).  With
+    // `return`s in the middle of the main loop the compiler's single-exit form of that loop merged the leaving paths into its
+    // latch and paid for it on the way round: all 24 held registers moved twice per group, and a wait for the just-requested
+    // samples (their registers were "merged" too).
+    auto leave = [&]() { asm volatile("s_endpgm" ::: "memory"); };
     auto expired = [&](unsigned since) -> bool {
         return static_cast<unsigned>(wall_clock64()) - since > P()->spin_ticks || is_dead() || aborted();
     };
@@ -259,8 +264,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     // -- as tagged halves.  Lane (blk % 16, q) of the wave that has claimed the signal fetches quantity q of the blocks blk and
     // blk + 16 (its 16-byte pairs l and l + 64: the mailbox is laid out for exactly that), adds them in that order and runs
     // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.
-    // the claim is this wave's: look at the mailbox until both of the lane's blocks are there; 0 = the launch was given up
-    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) -> int {
+    // the claim is this wave's: look at the mailbox until both of the lane's blocks are there
+    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) {
         // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
         __builtin_amdgcn_s_setprio(3);
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
@@ -281,10 +286,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
                     }
                 }
             if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
-            if ((polls & 7u) == 7u && expired(t0)) {
-                __builtin_amdgcn_s_setprio(0);
-                gave_up(); return 0;
-            }
+            if ((polls & 7u) == 7u && expired(t0)) { gave_up(); leave(); }
             __builtin_amdgcn_s_sleep(8);
         }
         // stats_from_blocks(): lane (blk % 16, q) adds its blocks blk, blk + 16 in that order, then stats_finish
@@ -302,23 +304,23 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         }
         wave_sync();
         __builtin_amdgcn_s_setprio(0);
-        return 1;
     };
-    // a wave cannot go on without a signal's statistics: a sibling's result, or this wave resolves; 0 = the launch was given up
-    auto signal_statistics = [&](int ko) -> int {
+    // a wave cannot go on without a signal's statistics: a sibling's result, or this wave resolves (a wave that finds the launch
+    // given up does not come back)
+    auto signal_statistics = [&](int ko) {
 #if defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2)      // development: nobody waits, nobody resolves (results invalid)
-        return 1;
+        return;
 #endif
-        if (stats_ready(ko)) return 1;
+        if (stats_ready(ko)) return;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned t0 = static_cast<unsigned>(wall_clock64());
         for (unsigned spins = 0;; ++spins) {
-            if ((spins & 15u) == 0u && try_claim(ko)) return resolve_owned(ko, t0, lane_r);
-            if ((spins & 31u) == 31u && expired(t0)) { gave_up(); return 0; }
-            if (is_dead()) return 0;
+            if ((spins & 15u) == 0u && try_claim(ko)) { resolve_owned(ko, t0, lane_r); return; }
+            if ((spins & 31u) == 31u && expired(t0)) { gave_up(); leave(); }
+            if (is_dead()) leave();
             __builtin_amdgcn_s_sleep(4);
-            if (stats_ready(ko)) return 1;
+            if (stats_ready(ko)) return;
         }
     };
 
@@ -396,13 +398,15 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         tile = canon_land<false>(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t, ((g_d + cg0) & ~3) * 16, n);
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
-    // 0: go on, 1: the list is done, 2: the launch was given up
     int slot = 0;                                        // the slot this step fills (steps take the slots in turn)
-    auto step = [&]() -> int {
+    draw(-1);
+    if (saw_dead) return;
+    if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
+    for (;;) {
+        if (saw_dead) leave();
         if (!c_valid) {                                  // slow path: nothing landed -- the wave holds nothing unpublished
-            if (!d_valid) draw(-1);
-            if (saw_dead) return 2;
-            if (!d_valid) return 1;
+            if (!d_valid) { draw(-1); if (saw_dead) leave(); }
+            if (!d_valid) break;                         // the list is done (the loop's only exit)
             land();
         }
         int lane_o = lane;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         //  exec goes to the kernels queued behind it, which have it -- same bits as on every path)
         if (__builtin_expect(tile.mean_s != tile.mean_s, 0)) {
             if (lane == 0) __hip_atomic_store((gu32*)(P()->fallbacks) + 1, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the reason, for the host)
-            gave_up(); return 2;
+            gave_up(); leave();
         }
 #ifndef HSS_T16_NO_LAGPRIO
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
@@ -473,12 +477,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             }
         }
         draw(ko_cur);
-        if (saw_dead) return 2;
         // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in
         int ko_o = 0;
         static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
         const bool full = nheld == DEPTH;
-        if (full) { if (signal_statistics(ko_o) == 0) return 2; }
+        if (full) signal_statistics(ko_o);
         else ++nheld;
         static_for<DEPTH>([&](auto S) {
             constexpr int sl = decltype(S)::value;
@@ -490,26 +493,14 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         });
         slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
         wave_sync();
-        return 0;
-    };
-    draw(-1);
-    if (saw_dead) return;
-    if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
-    int rc = 0;
-    do { rc = step(); } while (rc == 0);
-    if (rc == 2) return;
+    }
     // ---- the list is done: the held groups leave, oldest first
     for (int i = 0; i < nheld; ++i) {
         const int so = (slot + DEPTH - nheld + i) % DEPTH;
-        bool ok = true;
         static_for<DEPTH>([&](auto S) {
             constexpr int sl = decltype(S)::value;
-            if (so == sl) {
-                if (signal_statistics(ko_hs[sl]) == 0) ok = false;
-                else emit_held(held[sl], ko_hs[sl], g_hs[sl]);
-            }
+            if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(held[sl], ko_hs[sl], g_hs[sl]); }
         });
-        if (!ok) return;
     }
 }
 
