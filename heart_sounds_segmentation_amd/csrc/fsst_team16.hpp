@@ -442,10 +442,15 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
             const int pos = g_cur & (cpc - 1);           // position among the CU's groups of this signal
             const int ps = ko_cur & (PSLOTS - 1);
             float* pe = part_lds + (ps * kT16MaxCpc + pos) * kT16PartFloats;
-            const bool odd = lane_o & 1;
-            const int word = odd ? 4 + (lane_o >> 4) : (lane_o >> 4);
-            const float val = odd ? ((lane_o >> 4) ? piv.y : piv.x) : w;
-            if ((lane_o & 15) == 0 || ((lane_o & 15) == 1 && lane_o < 32)) pe[word] = val;
+            {   // the first lane of each row writes its row's sum, lane 0 the pivot pair: two stores under literal exec masks (the
+                // predicates as compares and selects were 20 instructions; LDS operations of a wave execute in order, the ones
+                // issued here only make the compiler's own counts conservative)
+                const unsigned pa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)pe)) + (static_cast<unsigned>(lane_o) >> 4) * 4u;
+                unsigned long long keep;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\tds_write_b32 %1, %2\n\t"
+                             "s_mov_b64 exec, 1\n\tds_write_b64 %1, %3 offset:16\n\ts_mov_b64 exec, %0"
+                             : "=&s"(keep) : "v"(pa), "v"(w), "v"(piv) : "memory");
+            }
             wave_sync();
             const int blk = g_cur >> 2, bfirst = blk << 2;                       // kStatBlock = 4
             const int expect = min(kStatBlock, G - bfirst);
