@@ -437,14 +437,29 @@ __device__ __forceinline__ void canon_image_to(const f2* own_base, const unsigne
     unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
     asm volatile("" : "+s"(obase));                      // ONE scalar base: each cell is then "offset + base", no second add
     const f2 sc = {inv, inv};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    static_for<3>([&](auto I) {
+        constexpr int i = decltype(I)::value;
         const unsigned pk = ppk[i * 64 + lane_o];
         const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
         const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
         const f2 lo = f2{q0[0], q0[2]} * sc, hi = f2{q1[0], q1[2]} * sc;
         sink(i, f4{lo.x, lo.y, hi.x, hi.y});
-    }
+    });
+}
+// The same gather, the pairs handed over UNSCALED with their float4's index as a compile-time constant (fsst_team16_kernel scales them
+// into fixed registers)
+template <int KLO, int KC, class Sink>
+__device__ __forceinline__ void canon_image_raw(const f2* own_base, const unsigned* ppk, int lane_o, Sink sink)
+{
+    unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
+    asm volatile("" : "+s"(obase));
+    static_for<3>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const unsigned pk = ppk[i * 64 + lane_o];
+        const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
+        const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
+        sink(I, f2{q0[0], q0[2]}, f2{q1[0], q1[2]});
+    });
 }
 template <int KLO, int KC>
 __device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* ppk, float inv, int lane_o, f4 (&o)[3])

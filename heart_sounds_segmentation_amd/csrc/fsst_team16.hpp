@@ -109,12 +109,42 @@ struct Team16Params {
     double inv_total, inv_total1;   // 1 / (K ncols), 1 / (K ncols - 1): the two divisions of stats_finish, made once on the host
 };
 
+
+// ---- The held images live in FIXED registers, v104 .. v127 (slot s, pair k: v[104 + 12 s + 2 k : +1]), outside the register allocator's
+// reach: the kernel is compiled for 104 VGPRs (amdgpu_num_vgpr) and every access is an inline-assembly statement that names its
+// register (the clobber lists make the code object reserve 128).  Left to the allocator, the 24 loop-carried registers were kept in one
+// place at the loop's head and in another across the transform: 24 register moves per group, a twentieth of the kernel's vector
+// instructions, whatever the source looked like (ring, strict first-in first-out, tied operands: profiles/r05_team_diet.txt).
+constexpr int kT16HeldBase = 104;
+#define HSS_T16_PAIRS(X) X(0, 104, 105) X(1, 106, 107) X(2, 108, 109) X(3, 110, 111) X(4, 112, 113) X(5, 114, 115) \
+                         X(6, 116, 117) X(7, 118, 119) X(8, 120, 121) X(9, 122, 123) X(10, 124, 125) X(11, 126, 127)
+// held pair P <- a * b (both packed pairs)
+template <int P>
+__device__ __forceinline__ void held_put(f2 a, f2 b)
+{
+#define HSS_T16_PUT(N, LO, HI) if constexpr (P == N) asm volatile("v_pk_mul_f32 v[" #LO ":" #HI "], %0, %1" :: "v"(a), "v"(b) : "v" #LO, "v" #HI);
+    HSS_T16_PAIRS(HSS_T16_PUT)
+#undef HSS_T16_PUT
+}
+// (held pair P - m.x) * m.y: the z-score of fsst_normalize_kernel, two roundings
+template <int P>
+__device__ __forceinline__ f2 held_zscore(f2 m)
+{
+    f2 d, e;
+#define HSS_T16_ZS(N, LO, HI) if constexpr (P == N) asm volatile("v_pk_add_f32 %0, v[" #LO ":" #HI "], %1 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(m));
+    HSS_T16_PAIRS(HSS_T16_ZS)
+#undef HSS_T16_ZS
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(e) : "v"(d), "v"(m));
+    return e;
+}
+
 // WPB waves per block (one block per CU), DEPTH group images held per wave (registers): (16, 2) is what the library launches
 template <int KLO, int KC, int WPB, int DEPTH>
-__global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Params p)
+__global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(52))) void fsst_team16_kernel(Team16Params p)
 {
     using C = CanonCfg<KLO, KC>;
-    static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 4, "whole waves per SIMD; at most four held groups");
+    static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 2, "whole waves per SIMD; two held groups (v104 .. v127)");
+    static_assert(DEPTH == 2, "the kernel is compiled for 104 allocatable registers + 24 fixed ones");
     constexpr int K = KC, ATAB = kCanonAtabFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = p.n;
@@ -328,26 +358,22 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     // its 3 streaming stores per lane.  {mean, 1 / std} of a float4's two column pairs come as ONE 16-byte LDS read: the signal's
     // statistics lie there three times -- (re, re), (re, im), (im, im) -- and which one float4 lane + 64 i needs is a constant of
     // the lane (cls_lds): no per-element selects.  The store address is scalar base + lane offset.
-    auto emit_held = [&](const f4 (&hv)[3], int ko_h, int g_h) {
+    auto emit_held = [&](auto SL, int ko_h, int g_h) {
+        constexpr int sl = decltype(SL)::value;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const unsigned cofs = cls_lds[lane_r];
         const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_h & smask));
-        auto zs = [](f2 v, f2 m) -> f2 {
-            f2 d, e;
-            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(m));
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(e) : "v"(d), "v"(m));
-            return e;
-        };
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko_h) * nteams;
         char* obase = reinterpret_cast<char*>(P()->out) + b * sig_bytes + static_cast<long long>(g_h) * (16 * 2 * K * 4);       // (wave-uniform)
         const unsigned voff = static_cast<unsigned>(lane_r) * 16u;
         const int nvalid = min(16, ncols - g_h * 16);
-        auto put = [&](int i) {
+        auto put = [&](auto I) {
+            constexpr int i = decltype(I)::value;
             const float4 tt = *reinterpret_cast<const float4*>(tb + ((cofs >> (8 * i)) & 0xffu));
-            const f2 lo = zs(f2{hv[i].x, hv[i].y}, f2{tt.x, tt.y});
-            const f2 hi = zs(f2{hv[i].z, hv[i].w}, f2{tt.z, tt.w});
+            const f2 lo = held_zscore<6 * sl + 2 * i>(f2{tt.x, tt.y});
+            const f2 hi = held_zscore<6 * sl + 2 * i + 1>(f2{tt.z, tt.w});
 #if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 2      // development: the arithmetic without the stores
             { f2 l2 = lo, h2 = hi; asm volatile("" :: "v"(l2), "v"(h2)); }
 #else
@@ -357,15 +383,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         if (__builtin_expect(nvalid == 16, 1)) {
             static_for<3>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                if constexpr (64 * (i + 1) <= 8 * K) put(i);
-                else if constexpr (64 * i < 8 * K) { if (lane_r + 64 * i < 8 * K) put(i); }
+                if constexpr (64 * (i + 1) <= 8 * K) put(I);
+                else if constexpr (64 * i < 8 * K) { if (lane_r + 64 * i < 8 * K) put(I); }
             });
         } else {
             asm volatile("");
             const int lim = nvalid * (K >> 1);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (lane_r + 64 * i < lim) put(i);
+            static_for<3>([&](auto I) { if (lane_r + 64 * decltype(I)::value < lim) put(I); });
         }
     };
 
@@ -375,7 +399,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
     // register moves per group at the loop head and a page of scalar bookkeeping; nothing is gained by a group leaving early.)
     int nheld = 0;
     int ko_hs[DEPTH], g_hs[DEPTH];
-    f4 held[DEPTH][3];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) { ko_hs[d] = 0; g_hs[d] = 0; }
 
@@ -491,8 +514,12 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         static_for<DEPTH>([&](auto S) {
             constexpr int sl = decltype(S)::value;
             if (slot == sl) {
-                if (full) emit_held(held[sl], ko_hs[sl], g_hs[sl]);
-                canon_image<KLO, KC>(own_base, ppk_lds, inv_cur, lane_o, held[sl]);
+                if (full) emit_held(S, ko_hs[sl], g_hs[sl]);
+                canon_image_raw<KLO, KC>(own_base, ppk_lds, lane_o, [&](auto I, f2 lo, f2 hi) {
+                    constexpr int i = decltype(I)::value;
+                    held_put<6 * sl + 2 * i>(lo, f2{inv_cur, inv_cur});
+                    held_put<6 * sl + 2 * i + 1>(hi, f2{inv_cur, inv_cur});
+                });
                 ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
             }
         });
@@ -504,7 +531,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void fsst_team16_kernel(Team16Pa
         const int so = (slot + DEPTH - nheld + i) % DEPTH;
         static_for<DEPTH>([&](auto S) {
             constexpr int sl = decltype(S)::value;
-            if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(held[sl], ko_hs[sl], g_hs[sl]); }
+            if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(S, ko_hs[sl], g_hs[sl]); }
         });
     }
 }
