@@ -34,6 +34,7 @@ constexpr int kCanonTileFrames = 64;                     // frames per aligned t
 constexpr int kCanonRecs = 192;                          // sample records per tile: 64 + 127, rounded up
 constexpr int kCanonOpFloats = 16 * 64 * 4;              // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
 constexpr int kCanonAtabFloats = kCanonOpFloats + 4 * 128;   // + {cos, sin}(2 pi m / 128) as float64 (rounding-tie path), 2 kB
+constexpr int kCanonLdsTabFloats = kCanonAtabFloats + 4 * 33 * 2;   // what the kernels keep in LDS: + the interior frame of the offset table ("Offsets"), 1 kB
 constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
 // (rounding ties: the bitmap of fsst_mfma128.hpp, "Rounding ties"; the float64 path reads the signal's own samples)
 constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
@@ -104,13 +105,18 @@ struct CanonTile {
 // every such group to the float64 path (2.59 vs 0.208 ms per 1024 windows).  The transform is linear, so a tile whose mean
 // carries at least half of its energy is staged WITHOUT it (records and scale of x - mean over the samples inside the signal:
 // the fold then works at the resolution of the content) and the mean's own spectrum is added where the sources are formed:
-// (V, Vd') of a source += mean x (V, Vd') of the all-ones frame, float64 on the host (hssfsst.hip): ONE table row per source
+// Z of a lane's two spectra += mean x Z of the all-ones frame, float64 on the host (hssfsst.hip): ONE table row per bin
 // for interior frames, a table of the 64 + 63 frames whose window reaches over the start / the end of the signal (both at once
 // for signals shorter than a window: ones = left + right - interior).  32 packed multiply-adds per lane and group, for such
-// tiles only.  (The mean's FOLD as the matrix instructions' C operand was tried first: its taps are as large as the offset,
+// tiles only, in one block between the spectra and the source stage.  (The mean's FOLD as the matrix instructions' C operand was tried first: its taps are as large as the offset,
 // they cancel only in the 16-point spectra -- in float32, at the offset's scale: 2.5e-4 on pcg + 100.)
-constexpr int kCanonYcFrame = 4 * 8 * 4 * 2;              // floats per frame: [lane group][stripe s][a1 | a2 | b1 | b2] as float2
-constexpr int kCanonZcFloats = kCanonYcFrame * (1 + 64 + 63);   // interior | left edge, output columns 0..63 | right edge, 0..62 samples to the end
+constexpr int kCanonYcGroup = 33;                         // float2 per lane group: za[0..15] | zb[0..15] | pad (the four lane groups of a wave read 264 bytes apart: different LDS banks)
+constexpr int kCanonYcFrame = 4 * kCanonYcGroup * 2;      // floats per frame: [lane group][za[0..15] | zb[0..15] | -] as float2 (the lane's two 16-point spectra)
+constexpr int kCanonYcRight = 80;                         // right-edge frames tabulated: 0..62 samples to the end, then 17 copies of the interior (a group of 16 frames that
+                                                          // reaches into the last 63 columns reads one table whatever its first frame)
+// interior [lane group][33] | left edge [lane group][entry][output column 0..63] | right edge [lane group][entry][samples to the end 0..79], float2 each:
+// the 16 lanes of a lane group (consecutive frames) read consecutive words of the edge tables
+constexpr int kCanonZcFloats = kCanonYcFrame + 4 * 32 * 64 * 2 + 4 * 32 * kCanonYcRight * 2;
 constexpr float kMeanTheta = 0.5f;                       // the mean is taken out when S1^2 >= kMeanTheta n E
 #ifndef HSS_OFFERR
 #define HSS_OFFERR 0.0625f
@@ -132,7 +138,9 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
 #pragma unroll
     for (int k = 0; k < 3; ++k) { e2 = fmaf(sreg[k], sreg[k], e2); s1 += sreg[k]; }
     const int inside = min(t0 + 128, n) - max(t0 - 64, 0);
-    const TileEnergy te = tile_energy(e2, s1, static_cast<float>(max(inside, 0)));
+    TileEnergy te = tile_energy(e2, s1, 0.0f);           // (E and S1: the reduction of every canonical-band kernel; the count does not ride along)
+    te.C = static_cast<float>(max(inside, 0));
+    te.dcdom = te.E > 0.0f && te.S1 * te.S1 >= kDcTheta * te.C * te.E;
     float E = te.E, mean = 0.0f, Edc = 0.0f;
     float x[3] = {sreg[0], sreg[1], sreg[2]};
     if (__builtin_expect(te.E > 0.0f && te.S1 * te.S1 >= kMeanTheta * te.C * te.E, 0)) {
@@ -264,6 +272,59 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     fft_n<NT>(zb);
 #endif
     CPROBE(1);
+    // ("Offsets" above) a tile staged without its mean: + mean x the spectrum of the all-ones frame, ONE block between the spectra and
+    // the source stage under one wave-uniform branch (round 4 added it to the mixed pairs of every stripe under eight branches, which
+    // cost the plain path of the team kernel 4 %).  Interior groups: 32 constants per lane group from the first frame's copy in LDS; a group
+    // at an end of the signal: left + right - interior of the per-frame tables in global memory (8 of a 2000-sample signal's 125 groups).
+    if constexpr (OFFS) {
+        if (__builtin_expect(tile.mean_s != 0.0f, 0)) {
+            int lane_f = lane_o;
+            asm volatile("" : "+v"(lane_f));
+            const int gq = (lane_f >> 4) & 3;
+            const f2 mm = {tile.mean_s, tile.mean_s};
+            const f2* zg = reinterpret_cast<const f2*>(zc) + gq * kCanonYcGroup;
+            if (tg >= 64 && tg + 15 + 63 <= n - 1) {     // (wave-uniform) interior: the constants' copy in LDS (broadcast reads)
+                const f2* zl = reinterpret_cast<const f2*>(atab + kCanonAtabFloats) + gq * kCanonYcGroup;
+                static_for<NT>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    za[i] = pk_fma(zl[i], mm, za[i]);
+                    zb[i] = pk_fma(zl[NT + i], mm, zb[i]);
+                });
+            } else {
+                // a group at an end of the signal: the frame's own constants -- left-edge table by output column, right-edge table by samples
+                // to the end (both, less the interior, for a signal shorter than a window and a half).  Eight entries at a time: left alone
+                // the scheduler requests all of them first and spills the spectra.
+                const int tf = tg + (lane_f & 15);
+                const int rr = min(max(n - 1 - tf, 0), kCanonYcRight - 1);       // (a frame behind the signal's end belongs to no output column)
+                const bool left = tg < 64, both = left && tg + 15 + 63 > n - 1;      // (wave-uniform)
+                // scalar table base + one lane offset per table: every load is "saddr + voffset" (per-lane 64-bit pointers beside the 64
+                // registers of the spectra were what spilled)
+                const char* lbase = reinterpret_cast<const char*>(zc + kCanonYcFrame);
+                const char* rbase = lbase + 4 * 32 * 64 * 8;
+                const unsigned lofs = static_cast<unsigned>(gq * (32 * 64) + min(tf, 63)) * 8u, rofs = static_cast<unsigned>(gq * (32 * kCanonYcRight) + rr) * 8u;
+                const char* b1 = left ? lbase : rbase;
+                const unsigned o1 = left ? lofs : rofs, st1 = (left ? 64u : static_cast<unsigned>(kCanonYcRight)) * 8u;
+                auto ent1 = [&](int e) -> f2 { return *reinterpret_cast<const f2*>(b1 + static_cast<size_t>(e) * st1 + o1); };
+                auto ent2 = [&](int e) -> f2 { return *reinterpret_cast<const f2*>(rbase + static_cast<size_t>(e) * (kCanonYcRight * 8) + rofs); };
+                if (!both) {
+                    static_for<8>([&](auto Q) {
+                        constexpr int q0 = 2 * decltype(Q)::value;
+                        const f2 c0 = ent1(q0), c1 = ent1(q0 + 1), c2 = ent1(NT + q0), c3 = ent1(NT + q0 + 1);
+                        za[q0] = pk_fma(c0, mm, za[q0]); za[q0 + 1] = pk_fma(c1, mm, za[q0 + 1]);
+                        zb[q0] = pk_fma(c2, mm, zb[q0]); zb[q0 + 1] = pk_fma(c3, mm, zb[q0 + 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
+                    static_for<NT>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        const f2 ca = ent1(i) + ent2(i) - zg[i], cb = ent1(NT + i) + ent2(NT + i) - zg[NT + i];
+                        za[i] = pk_fma(ca, mm, za[i]); zb[i] = pk_fma(cb, mm, zb[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+            }
+        }
+    }
 
     // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
     unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
@@ -273,26 +334,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
     f2* row_disp = disp_base + j * C::LDF;
     float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
-    // ("Offsets" above) the lane's entries of the offset table for its frame (output column tg + j): interior, or left + right - interior
-    // (everything the offset term needs is made from the lane id INSIDE its branch, one table entry fetched and used at a time:
-    //  offsets, pointers or a stripe's four entries held across the stripes pushed this 128-register code into scratch in its
-    //  hot path)
-    const bool has_off = OFFS && tile.mean_s != 0.0f;    // (wave-uniform)
-    auto offset_term = [&](int e) -> f2 {                // mean x entry e of the lane's 32 for its frame (output column tg + j)
-        int lane_f = lane_o;
-        asm volatile("" : "+v"(lane_f));
-        const int gq = (lane_f >> 4) & 3, tf = tg + (lane_f & 15), rr = n - 1 - tf;      // frames from the start / samples to the end
-        const char* zb8 = reinterpret_cast<const char*>(zc) + 8 * e;
-        const unsigned oti = static_cast<unsigned>(gq) * 256u;
-        f2 c = *reinterpret_cast<const f2*>(zb8 + oti);
-        if (!(tg >= 64 && tg + 15 + 63 <= n - 1)) {      // (wave-uniform) a group at an end of the signal: left + right - interior
-            const unsigned otl = (tf < 64) ? oti + static_cast<unsigned>(1 + tf) * (kCanonYcFrame * 4u) : oti;
-            const unsigned otr = (rr < 63 && rr >= 0) ? oti + static_cast<unsigned>(65 + rr) * (kCanonYcFrame * 4u) : oti;
-            c = *reinterpret_cast<const f2*>(zb8 + otl) + *reinterpret_cast<const f2*>(zb8 + otr) - c;
-        }
-        float m = tile.mean_s;
-        return c * f2{m, m};
-    };
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 4
     {   f2 accz = {0.0f, 0.0f};
         static_for<NT>([&](auto I) { accz += za[decltype(I)::value] + zb[decltype(I)::value]; });
@@ -309,12 +350,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
         f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
         f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
-        if (__builtin_expect(has_off, 0)) {                  // + mean x (the all-ones frame's V, Vd' of these two sources)
-            a1 += offset_term(4 * s + 0); __builtin_amdgcn_sched_barrier(0);
-            a2 += offset_term(4 * s + 1); __builtin_amdgcn_sched_barrier(0);
-            b1 += offset_term(4 * s + 2); __builtin_amdgcn_sched_barrier(0);
-            b2 += offset_term(4 * s + 3); __builtin_amdgcn_sched_barrier(0);
-        }
         const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
         if constexpr (STA) { ownA[16 * s] = a1.x; ownA[16 * s + 1] = a2.x; mx = fmaxf(mx, dna.x); }
         if constexpr (STB) { ownB[16 * s] = b1.x; ownB[16 * s + 1] = b2.x; mx = fmaxf(mx, dnb.x); }
@@ -526,7 +561,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int WPB = 16, K = KC, GPCF = kCanonTileFrames / 16;
-    constexpr int ATAB = kCanonAtabFloats;
+    constexpr int ATAB = kCanonLdsTabFloats;
     constexpr int CTL = FUSED ? kCanonCtlFusedFloats : kCanonCtlFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (p.gate != nullptr && *p.gate != p.gate_val) return;          // (uniform: the team kernel this launch backs up did not give up)

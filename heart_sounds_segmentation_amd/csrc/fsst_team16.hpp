@@ -68,20 +68,23 @@ constexpr int kT16BlockWords = 8;            // tagged 8-byte words per BLOCK of
                                              // float64 sums (sum re, sum re^2, sum im, sum im^2), each as {high, low} half
 constexpr int kT16MaxBlocks = kFusedMaxGroups / kStatBlock;      // 32 blocks per signal
 constexpr int kT16MaxCpc = 8;                // groups of a signal per CU (two blocks)
-constexpr int kT16MaxSlots = 64;             // statistics slots per CU / mailbox slots per team (signal ordinal mod slots)
+constexpr int kT16MaxSlots = 64;             // statistics slots per CU / mailbox slots per team (signal ordinal mod slots); 32 where the LDS is short
 constexpr int kT16StatFloats = 12;           // a signal's statistics in LDS: three float4 {mean, 1/std} pairs -- (re, re), (re, im), (im, im): the
                                              // z-score of a float4 of the image reads the one its two column pairs need (emit_held)
-constexpr int kT16CtlBase = 16 + 64 + 192 + 2 * kT16MaxSlots + kT16StatFloats * kT16MaxSlots;
-                                             // [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets |
-                                             // ready[slots], claim[slots] | statistics[slots][3] float4
+// [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets | ready[slots], claim[slots] | statistics[slots][3] float4
+constexpr int t16_ctl_base(int slots) { return 16 + 64 + 192 + 2 * slots + kT16StatFloats * slots; }
 // ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
-constexpr int t16_ctl_floats(int pslots) { return kT16CtlBase + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
-// PSLOTS for a band: what the LDS beside 16 wave regions leaves (32 signals deep where it fits, 16 for the widest band)
+constexpr int t16_ctl_floats(int pslots, int slots) { return t16_ctl_base(slots) + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
+// what the LDS beside the tables and 16 wave regions leaves: partials 32 signals deep and 64 statistics slots where they fit
+template <int KLO, int KC>
+constexpr int t16_room() { return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(); }
+template <int KLO, int KC>
+constexpr int t16_slots() { return t16_room<KLO, KC>() >= t16_ctl_floats(16, kT16MaxSlots) ? kT16MaxSlots : kT16MaxSlots / 2; }
 template <int KLO, int KC>
 constexpr int t16_pslots()
 {
-    constexpr int room = 160 * 1024 / 4 - kCanonAtabFloats - 16 * CanonCfg<KLO, KC>::wave_floats();
-    return room >= t16_ctl_floats(32) ? 32 : room >= t16_ctl_floats(16) ? 16 : 0;
+    constexpr int room = t16_room<KLO, KC>(), sl = t16_slots<KLO, KC>();
+    return room >= t16_ctl_floats(32, sl) ? 32 : room >= t16_ctl_floats(16, sl) ? 16 : 0;
 }
 
 struct Team16Params {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     using C = CanonCfg<KLO, KC>;
     static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 2, "whole waves per SIMD; two held groups (v104 .. v127)");
     static_assert(DEPTH == 2, "the kernel is compiled for 104 allocatable registers + 24 fixed ones");
-    constexpr int K = KC, ATAB = kCanonAtabFloats;
+    constexpr int K = KC, ATAB = kCanonLdsTabFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = p.n;
     const int lane = threadIdx.x & 63;
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64] byte i: which of a signal's three float4 statistics float4 lane + 64 i reads
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // [3][64]
     unsigned* ready = reinterpret_cast<unsigned*>(smem + ATAB + 272);        // [slots] epoch (signal ordinal + 1) of the statistics in fin[]
-    unsigned* claim = ready + kT16MaxSlots;                                  // [slots] epoch some wave of this CU is resolving / has resolved
-    float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * kT16MaxSlots);      // [slots][3]
-    constexpr int PSLOTS = t16_pslots<KLO, KC>();
+    constexpr int MS = t16_slots<KLO, KC>(), PSLOTS = t16_pslots<KLO, KC>();
+    unsigned* claim = ready + MS;                                            // [slots] epoch some wave of this CU is resolving / has resolved
+    float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * MS);     // [slots][3]
     static_assert(PSLOTS >= 16, "the CU's own partials need LDS beside the wave regions");
-    float* part_lds = smem + ATAB + kT16CtlBase;                             // [PSLOTS][kT16MaxCpc][6]
+    float* part_lds = smem + ATAB + t16_ctl_base(MS);                        // [PSLOTS][kT16MaxCpc][6]
     int* pcnt_lds = reinterpret_cast<int*>(part_lds + PSLOTS * kT16MaxCpc * kT16PartFloats);   // [PSLOTS][2] partials delivered per block
-    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS) + wv * C::wave_floats();
+    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS, MS) + wv * C::wave_floats();
     u2* xrec = reinterpret_cast<u2*>(wbase);
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
     f2* disp_base = own_base + 16 * C::LD;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     if (lane < 4) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
-    for (int i = threadIdx.x; i < 2 * kT16MaxSlots; i += 64 * WPB) ready[i] = 0u;        // ready[], claim[]
+    for (int i = threadIdx.x; i < 2 * MS; i += 64 * WPB) ready[i] = 0u;       // ready[], claim[]
     if (threadIdx.x < 2 * PSLOTS) pcnt_lds[threadIdx.x] = 0;
     // Block identity = ARRIVAL number ("Giving up" above)
     if (threadIdx.x == 64)
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     auto land = [&]() {
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-        tile = canon_land<false>(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t, ((g_d + cg0) & ~3) * 16, n);
+        tile = canon_land<true>(sreg, xrec, P()->r2scale_s, P()->inv_c, lane_t, ((g_d + cg0) & ~3) * 16, n);
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
     int slot = 0;                                        // the slot this step fills (steps take the slots in turn)
@@ -436,12 +439,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         asm volatile("" : "+v"(lane_o));
         const long long b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
         const int tg = P()->col0 + g * 16;
-        // (a tile that rides on an offset -- fsst_canon128.hpp "Offsets" -- needs a term this kernel has no register for: the whole
-        //  exec goes to the kernels queued behind it, which have it -- same bits as on every path)
-        if (__builtin_expect(tile.mean_s != tile.mean_s, 0)) {
-            if (lane == 0) __hip_atomic_store((gu32*)(P()->fallbacks) + 1, P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the reason, for the host)
-            gave_up(); leave();
-        }
 #ifndef HSS_T16_NO_LAGPRIO
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
             // (what the wave's own next ticket says about the counter -- a group time old, but no trip to LDS)
@@ -449,7 +446,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
-        canon_group<KLO, KC, HSS_T16_TAPB, false>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
+        canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
                                            P()->x + b * P()->xstride, n, tg, P()->atab + kCanonAtabFloats);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;

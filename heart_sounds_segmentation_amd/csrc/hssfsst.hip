@@ -240,7 +240,6 @@ struct hssfsst_plan {
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
-    unsigned seen_offset = 0; int offset_hold = 0;           // the last team launch seen to give up over an OFFSET tile; execs left that skip the team kernel
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
     int team16_cus = 0;                                      // CUs usable by the team kernel (fsst_team16.hpp; 0 = not queried yet, -1 = none)
     char last_kernel[112] = "";                              // the transform kernel of the last exec: instantiation, waves per block, grid (hssfsst_plan_last_kernel)
@@ -527,7 +526,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
     // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
     constexpr int PSLOTS = t16_pslots<KLO, KC>();        // signals whose partials a CU keeps in LDS at a time
-    size_t lds = (kCanonAtabFloats + t16_ctl_floats(PSLOTS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    constexpr int MS = t16_slots<KLO, KC>();             // statistics / mailbox slots the kernel's LDS has room for
+    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS, MS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     if (lds < 84 * 1024) lds = 84 * 1024;
     auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
@@ -561,7 +561,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     const int lead = (held_pos + G / T - 1) / (G / T) + 1;
     int slots = 8;
     while (slots < 2 * lead + 2) slots *= 2;
-    if (slots > kT16MaxSlots) return 0;
+    if (slots > MS) return 0;
     if (lead + 1 > PSLOTS) return 0;                     // (very short signals: more signals in flight per CU than its LDS keeps partials for)
     int rc;
     if ((rc = ensure_status(pl)) != 0) return rc;
@@ -645,8 +645,8 @@ template <int KLO, int KC>
 int launch_canon_band(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
     constexpr int WPB = 16;
-    const size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
-    static_assert((hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFloats + 16 * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float) <= 160 * 1024, "16 wave regions must fit");
+    const size_t lds = (hssfsst::kCanonLdsTabFloats + hssfsst::kCanonCtlFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    static_assert((hssfsst::kCanonLdsTabFloats + hssfsst::kCanonCtlFloats + 16 * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float) <= 160 * 1024, "16 wave regions must fit");
     auto kern = hssfsst::fsst_canon_kernel<KLO, KC, false>;
     static std::atomic<unsigned long long> lds_ok{0};
     if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
@@ -681,7 +681,7 @@ int launch_canon_fused_band(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t
 {
     constexpr int WPB = 16, GPC = hssfsst::kCanonTileFrames / 16;
     if (ngroups > hssfsst::kFusedMaxGroups || (ngroups + GPC - 1) / GPC < hssfsst::kFusedMinChunks) return 0;
-    constexpr size_t lds = (hssfsst::kCanonAtabFloats + hssfsst::kCanonCtlFusedFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    constexpr size_t lds = (hssfsst::kCanonLdsTabFloats + hssfsst::kCanonCtlFusedFloats + static_cast<size_t>(WPB) * hssfsst::CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
     // (rows 2..25: 16 wave regions of 8.6 kB and the two signals' partials do not fit the 160 KiB together: team kernel or two launches)
     if constexpr (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     else {
@@ -697,9 +697,8 @@ int launch_canon_fused_band(hssfsst_plan* pl, hssfsst::Core128Params cp, int64_t
     if (pl->fused_slots < 1) return 0;
     int64_t grid = pl->fused_slots;
     const int64_t rounds = (batch + grid - 1) / grid;
-    // (gated = behind a team launch: almost always the gate is closed and 64 blocks keep the empty launch short -- unless this
-    //  plan's data has been seen to ride on offsets: then the team kernel hands execs over and the fallback is the real thing)
-    if (gated) grid = (pl->seen_offset != 0u) ? (batch < grid ? batch : grid) : (batch < 64 ? batch : 64);
+    // (gated = behind a team launch: almost always the gate is closed and 64 blocks keep the empty launch short)
+    if (gated) grid = batch < 64 ? batch : 64;
     else if (batch < grid || rounds * grid * 100 > batch * 112) return 0;
     if (int rcs = ensure_status(pl)) return rcs;
     cp.status = pl->d_status;
@@ -760,15 +759,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
-        // (signals that ride on an offset -- fsst_canon128.hpp "Offsets" -- make the team kernel hand the exec to the kernels behind
-        //  it; the host sees that in pinned memory an exec or two later and sends the plan's next 64 STACK execs there directly)
-        if (pl->h_fallback && !team_only) {
-            const unsigned now = pl->h_fallback[1];
-            if (now != pl->seen_offset) { pl->seen_offset = now; pl->offset_hold = 64; }
-        }
-        const bool hold = pl->offset_hold > 0 && !team_only;
-        if (hold) --pl->offset_hold;
-        if (!no_team && !hold && canon16) {
+        if (!no_team && canon16) {
             rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
@@ -1164,13 +1155,15 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                         std::memcpy(&bits, &pick, sizeof(bits));
                         ht[(static_cast<size_t>(n) * 64 + l) * 8 + h] = bits;
                     }
-            // fsst_canon128.hpp "Offsets": what a frame of ones contributes to the (V, Vd') pairs the source stage forms.
+            // fsst_canon128.hpp "Offsets": what a frame of ones contributes to the spectra the source stage starts from.
             //   Zc[k] = (-1)^k 0.5 sum_{m inside the signal} (w + i dw')[m] e^{-2 pi i k m / 128}  (x cs: plane units),
-            // lane group g, stripe s: source A = k 8 s + g with partner 128 - k, source B = k 8 s + (g ? 8 - g : 4) with its partner;
-            //   a1 = (P.re + X.re, P.re - X.re), a2 = (X.im - P.im, X.im + P.im)  (mix_re / mix_im of fsst_mfma128.hpp), b1, b2 alike.
+            // lane group g holds the classes g and (g ? 8 - g : 4): za[s] = Z[8 s + g], zb[s] = Z[8 s + (g ? 8 - g : 4)], s = 0..15.
             // Frame 0 = interior (every m), 1 + t = the frame of output column t < 64 (m >= 64 - t), 65 + r = the frame r < 63 samples
-            // before the end (m <= r + 64); entry [frame][g][s][a1 | a2 | b1 | b2] as float2
+            // before the end (m <= r + 64).  Layout (fsst_canon128.hpp kCanonZcFloats): interior [g][za[0..15] | zb[0..15] | -];
+            // left edge [g][entry][t]; right edge [g][entry][r], r = 63 .. 79 = the interior once more
             std::vector<float> zc(static_cast<size_t>(hssfsst::kCanonZcFloats), 0.0f);
+            float* zleft = zc.data() + hssfsst::kCanonYcFrame;
+            float* zright = zleft + 4 * 32 * 64 * 2;
             for (int fr = 0; fr < 1 + 64 + 63; ++fr) {
                 const int m0 = (fr >= 1 && fr <= 64) ? 64 - (fr - 1) : 0;
                 const int m1 = (fr >= 65) ? (fr - 65) + 64 : 127;
@@ -1187,13 +1180,17 @@ int hssfsst_plan_create(hssfsst_plan** out, int device, int nwin, const double* 
                     zr[k] = sg * re * cs; zi[k] = sg * im * cs;
                 }
                 for (int gg = 0; gg < 4; ++gg)
-                    for (int s8 = 0; s8 < 8; ++s8) {
-                        const int ks[2] = {8 * s8 + gg, 8 * s8 + (gg ? 8 - gg : 4)};
-                        float* e = zc.data() + (static_cast<size_t>(fr) * hssfsst::kCanonYcFrame) + ((gg * 8 + s8) * 4) * 2;
+                    for (int s16 = 0; s16 < 16; ++s16) {
+                        const int ks[2] = {8 * s16 + gg, 8 * s16 + (gg ? 8 - gg : 4)};       // the lane group's two classes: za[s], zb[s]
                         for (int ab = 0; ab < 2; ++ab) {
-                            const int k = ks[ab], kp = (128 - k) & 127;
-                            e[4 * ab + 0] = static_cast<float>(zr[kp] + zr[k]); e[4 * ab + 1] = static_cast<float>(zr[kp] - zr[k]);     // mix_re
-                            e[4 * ab + 2] = static_cast<float>(zi[k] - zi[kp]); e[4 * ab + 3] = static_cast<float>(zi[k] + zi[kp]);     // mix_im
+                            const int ent = ab * 16 + s16;
+                            const float vr = static_cast<float>(zr[ks[ab]]), vi = static_cast<float>(zi[ks[ab]]);
+                            auto put = [&](float* e) { e[0] = vr; e[1] = vi; };
+                            if (fr == 0) {
+                                put(zc.data() + (gg * hssfsst::kCanonYcGroup + ent) * 2);
+                                for (int r = 63; r < hssfsst::kCanonYcRight; ++r) put(zright + ((gg * 32 + ent) * hssfsst::kCanonYcRight + r) * 2);
+                            } else if (fr <= 64) put(zleft + ((gg * 32 + ent) * 64 + (fr - 1)) * 2);
+                            else put(zright + ((gg * 32 + ent) * hssfsst::kCanonYcRight + (fr - 65)) * 2);
                         }
                     }
             }

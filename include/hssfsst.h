@@ -129,13 +129,11 @@ int hssfsst_plan_last_kernel(const hssfsst_plan* plan, char* buf, int len);
 #define HSSFSST_ZPATH_TEAM 3
 int hssfsst_plan_set_zpath(hssfsst_plan* plan, int zpath);
 
-/* The team kernel gives a launch up in two cases, both computed by the kernels the library queues behind every team launch,
- * gated on exactly that event: same result, no error.  (1) A signal rides on an offset (a tile's mean carries half of its
- * energy): the term that keeps such tiles in float32 lives in the other kernels; the plan's next 64 STACK execs then skip the
- * team kernel.  (2) Its blocks wait for each other; when they are kept apart (other processes' kernels on the same GPU) a wait
- * runs out of time (0.5 ms), the launch gives itself up and the exec is computed by the two-launch kernels that the library
- * queues behind every team launch, gated on exactly that event: same result, no error.  This returns how many distinct team
- * launches of the plan were seen to have fallen back so far (sampled whenever it is called: call it after a synchronisation). */
+/* The team kernel's blocks wait for each other; when they are kept apart (other processes' kernels on the same GPU, two launches
+ * of one plan on different streams) a wait runs out of time (0.5 ms), the launch gives itself up and the exec is computed by the
+ * kernels the library queues behind every team launch, gated on exactly that event: same result, no error.  This returns how many
+ * distinct team launches of the plan were seen to have fallen back so far (sampled whenever it is called: call it after a
+ * synchronisation).  (Signals that ride on an offset no longer count here: since round 5 the team kernel computes them itself.) */
 int hssfsst_plan_fallbacks(hssfsst_plan* plan);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every

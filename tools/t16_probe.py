@@ -22,7 +22,7 @@ def main():
     plan = ctypes.c_void_p()
     rc = L.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1000.0, 1, 25.0, 200.0, 2)
     assert rc == 0, L.hssfsst_last_error()
-    X = torch.from_numpy(synth.pcg_windows(B, n)).cuda()
+    X = torch.from_numpy((synth.pcg_windows(B, n) + float(os.environ.get("T16_OFFSET", "0"))).astype(np.float32)).cuda()
     out = torch.empty((B, n, 44), dtype=torch.float32, device="cuda")
     for rd in range(int(os.environ.get("T16_ROUNDS", "4"))):
         L.hssfsst_plan_set_timing(plan, 1)
