@@ -254,6 +254,12 @@ struct hssfsst_plan {
     float* d_stats = nullptr;     size_t stats_cap = 0;      // floats (4 per signal)
     float* d_xstage = nullptr;    size_t xstage_cap = 0;     // floats
     float* d_ostage = nullptr;    size_t ostage_cap = 0;     // floats
+    // small host-to-host execs (the unchanged dataset loop: one 2000-sample frame per call): pinned, device-mapped staging that the
+    // kernels read and write in place
+    float* h_xpin = nullptr; float* d_xpin = nullptr; size_t xpin_cap = 0;
+    float* h_opin = nullptr; float* d_opin = nullptr; size_t opin_cap = 0;
+    bool defer_fallback = false;                             // this exec synchronises before it returns: no gated launches behind a team launch,
+    unsigned deferred_launch = 0, deferred_first = 0;        // the host looks at the pinned give-up word afterwards and redoes the exec itself
     long long* d_starts = nullptr; size_t starts_cap = 0;    // frame-list staging (hssfsst_exec_list with host starts)
     float* d_frames = nullptr;    size_t frames_cap = 0;     // frames gathered from a list, dense [batch][n]
     int timing = 0;
@@ -772,6 +778,12 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
                     HIP_TRY(hipEventRecord(evt, st));
                     pl->timing_closed = true;
                 }
+                if (pl->defer_fallback) {                // (exec_impl: a host-output exec synchronises anyway and checks the give-up word then)
+                    if (pl->deferred_launch == 0u) pl->deferred_first = pl->team_launch;
+                    pl->deferred_launch = pl->team_launch;
+                    *did_fuse = true;
+                    return 0;
+                }
                 pl->gate = pl->d_arrive + 1; pl->gate_val = pl->team_launch;
                 // ONE gated launch where the one-CU-per-signal kernel applies (signals of 16 .. 32 chunks; its batch
                 // conditions are about speed only): 4 us behind the team kernel instead of 11 for transform + statistics +
@@ -1229,6 +1241,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_stats) (void)hipFree(p->d_stats);
     if (p->d_xstage) (void)hipFree(p->d_xstage);
     if (p->d_ostage) (void)hipFree(p->d_ostage);
+    if (p->h_xpin) (void)hipHostFree(p->h_xpin);
+    if (p->h_opin) (void)hipHostFree(p->h_opin);
     if (p->d_starts) (void)hipFree(p->d_starts);
     if (p->d_frames) (void)hipFree(p->d_frames);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1382,7 +1396,30 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     const float* dx = x;
     float* dout = out;
     int rc;
-    if (!x_on_device) {
+    // Small host-to-host execs -- the reference's dataset loop calls the transform once per 2000-sample frame with CPU tensors
+    // (/root/reference/hss/datasets/heart_sounds.py:166-168,199-201) -- do not go through hipMemcpyAsync from / to pageable memory
+    // (two staged copies by the runtime, ~0.03 ms of a 0.068 ms call): the samples are copied into a pinned, device-mapped buffer
+    // that the kernels read in place, and where the output is written exactly once (every mode but a STACK whose z-score is a
+    // second pass over the features) the kernels store it into a pinned buffer too -- the mechanism of hssfsst_stream_step.
+    const bool tiny_in = !x_on_device && nx <= (static_cast<size_t>(1) << 16);
+    const bool tiny_out = tiny_in && !out_on_device && no <= (static_cast<size_t>(1) << 21) &&
+                          (p->mode != HSSFSST_MODE_STACK || (plan_is_canon(p) && (col0 & 15) == 0 && !debug_switches().no_team));
+    auto pin = [&](float** h, float** d, size_t* cap, size_t need) -> int {
+        if (*cap >= need) return 0;
+        if (*h) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipHostFree(*h)); *h = nullptr; *d = nullptr; *cap = 0; }
+        size_t c = 1 << 12;
+        while (c < need) c *= 2;
+        void* hp = nullptr; void* dp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, c * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        *h = static_cast<float*>(hp); *d = static_cast<float*>(dp); *cap = c;
+        return 0;
+    };
+    if (tiny_in) {
+        if ((rc = pin(&p->h_xpin, &p->d_xpin, &p->xpin_cap, nx)) != 0) return rc;
+        std::memcpy(p->h_xpin, x, nx * sizeof(float));
+        dx = p->d_xpin;
+    } else if (!x_on_device) {
         if ((rc = grow(reinterpret_cast<void**>(&p->d_xstage), &p->xstage_cap, nx, sizeof(float))) != 0) return rc;
         HIP_TRY(hipMemcpyAsync(p->d_xstage, x, nx * sizeof(float), hipMemcpyHostToDevice, st));
         dx = p->d_xstage;
@@ -1399,7 +1436,13 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         dx = p->d_frames;
         x_stride = n;
     }
-    if (!out_on_device) {
+    p->defer_fallback = false;
+    if (tiny_out) {
+        if ((rc = pin(&p->h_opin, &p->d_opin, &p->opin_cap, no)) != 0) return rc;
+        dout = p->d_opin;
+        p->defer_fallback = p->zpath_pref != HSSFSST_ZPATH_ONE_CU && !d_starts;
+        p->deferred_launch = 0u;
+    } else if (!out_on_device) {
         if ((rc = grow(reinterpret_cast<void**>(&p->d_ostage), &p->ostage_cap, no, sizeof(float))) != 0) return rc;
         dout = p->d_ostage;
     }
@@ -1562,7 +1605,26 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             p->ev_chunks.push_back(timed_chunks);
         }
     }
-    if (!out_on_device) {
+    if (tiny_out) {
+        HIP_TRY(hipStreamSynchronize(st));
+        p->defer_fallback = false;
+        if (p->deferred_launch != 0u) {
+            // no gated kernels were queued behind this exec's team launch: if that launch gave itself up (pinned word, written with
+            // system scope before the kernel ended), the exec is computed now by the kernels that would have been queued
+            const unsigned dl = p->deferred_launch, df = p->deferred_first;
+            p->deferred_launch = 0u;
+            const unsigned gu = p->h_fallback ? p->h_fallback[0] : 0u;      // (launch identities count up; 0 is never one)
+            if (gu != 0u && (df <= dl ? (gu >= df && gu <= dl) : (gu >= df || gu <= dl))) {
+                const int keep = p->zpath_pref;
+                p->zpath_pref = HSSFSST_ZPATH_ONE_CU;
+                rc = exec_impl(p, x, batch, n, x_stride, d_starts, x_len, col0, ncols, x_on_device, out, out_on_device, stream);
+                p->zpath_pref = keep;
+                return rc;
+            }
+        }
+        if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;
+        std::memcpy(out, p->h_opin, no * sizeof(float));
+    } else if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;

@@ -196,6 +196,18 @@ class FSST:
         Returns: ``stack`` -> float32 ``(n, 2K)``; ``abs`` -> float32 ``(n, K)``; otherwise
         complex64 ``(K, n)``.
         """
+        # the dataset loop's call -- a CPU float32 (n,) / (n, 1) frame, once per 2000 samples (heart_sounds.py:166-168,199-201) --
+        # goes straight to the C ABI: of a 0.057 ms call the generic path below spent 0.012 ms on conversions and checks
+        if (type(x) is torch.Tensor and x.dtype == torch.float32 and x.device.type == "cpu" and x.is_contiguous()
+                and not x.requires_grad and (x.ndim == 1 or (x.ndim == 2 and 1 in x.shape)) and x.numel() > 0):
+            plan = self._plan(self._device_index(x))
+            n, K, m = x.numel(), plan.K, plan.mode
+            if K > 0:
+                out = (torch.empty((K, n), dtype=torch.complex64) if m == _lib.MODE_RAW
+                       else torch.empty((n, K if m == _lib.MODE_ABS else 2 * K), dtype=torch.float32))
+                _lib.check(_lib.lib().hssfsst_exec_frames(plan.handle, x.data_ptr(), 1, n, n, 0, n, 0, out.data_ptr(), 0, None),
+                           "hssfsst_exec_frames")
+                return out
         x = self._as_f32(x)
         if x.ndim == 2 and 1 in x.shape:
             x = x.reshape(-1)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Where the time of one drop-in call goes: FSST.__call__ (CPU (2000, 1) tensor) vs the raw C-ABI exec on preallocated host buffers."""
+import ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heart_sounds_segmentation_amd import FSST, synth, _lib
+tf = FSST(1000, synth.kaiser_window(128, 0.5), truncate_freq=(25, 200), stack=True)
+fr = torch.from_numpy(synth.pcg_windows(1, 2000)[0]).reshape(2000, 1)
+y = tf(fr)
+def t(f, n=300):
+    for _ in range(20): f()
+    t0 = time.perf_counter()
+    for _ in range(n): f()
+    return (time.perf_counter() - t0) / n * 1e6
+print(f"FSST.__call__                      {t(lambda: tf(fr)):.1f} us")
+L = _lib.lib()
+plan = tf._plan(0)
+x = np.ascontiguousarray(fr.numpy().reshape(-1)); out = np.empty((2000, 44), np.float32)
+xp, op = ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data)
+print(f"hssfsst_exec host -> host (raw)    {t(lambda: L.hssfsst_exec(plan.handle, xp, 1, 2000, 0, op, 0, None)):.1f} us")
+xd = torch.from_numpy(x).cuda(); od = torch.empty((1, 2000, 44), device='cuda')
+xdp, odp = ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(od.data_ptr())
+def dev():
+    L.hssfsst_exec(plan.handle, xdp, 1, 2000, 1, odp, 1, None); torch.cuda.synchronize()
+print(f"hssfsst_exec device -> device + sync {t(dev):.1f} us")
+print(f"torch.empty((2000, 44))            {t(lambda: torch.empty((2000, 44))):.1f} us")
+a = np.empty((2000, 44), np.float32); b = np.ones((2000, 44), np.float32)
+print(f"352 kB host memcpy                 {t(lambda: np.copyto(a, b)):.1f} us")
+print("team launches that fell back:", L.hssfsst_plan_fallbacks(plan.handle))
