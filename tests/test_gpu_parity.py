@@ -813,7 +813,11 @@ print("PATH", path, "FALLBACKS", tf.fallbacks())
 # one-CU-per-signal kernel that backs the 2000-sample exec up
 got2 = tf.batch(torch.from_numpy(synth.pcg_windows(40, 500, seed=6)).cuda())
 print("PATH2", tf.check(), "FALLBACKS2", tf.fallbacks())
-torch.save((got.cpu(), got2.cpu()), sys.argv[1])
+# the dataset loop's call: ONE frame, CPU in / CPU out -- pinned staging, no gated launches queued behind the team launch: the
+# host looks at the give-up word after its synchronisation and redoes the exec itself
+one = tf(X[0].cpu().reshape(2000, 1))
+print("FALLBACKS3", tf.fallbacks(), "ONE_EQUALS_BATCH", bool(torch.equal(one, got[0].cpu())))
+torch.save((got.cpu(), got2.cpu(), one), sys.argv[1])
 """
 
 
@@ -833,8 +837,12 @@ def test_team_kernel_fallback_and_other_processes(tmp_path):
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
         assert "PATH 2 FALLBACKS 0" in outs["plain"][1] and "PATH 2 FALLBACKS 1" in outs["forced"][1] and "PATH 0" in outs["two"][1], [o[1] for o in outs.values()]
         assert "PATH2 2 FALLBACKS2 0" in outs["plain"][1] and "PATH2 2 FALLBACKS2 2" in outs["forced"][1], [o[1] for o in outs.values()]
-    for i in range(2):
+    for i in range(3):
         assert torch.equal(outs["plain"][0][i], outs["forced"][0][i]) and torch.equal(outs["plain"][0][i], outs["two"][0][i])
+    for o in outs.values():
+        assert "ONE_EQUALS_BATCH True" in o[1], o[1]
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert "FALLBACKS3 0" in outs["plain"][1] and "FALLBACKS3 3" in outs["forced"][1], [o[1] for o in outs.values()]
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "team_stress.py"), "3", "200"], cwd=root, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "exit codes [0, 0, 0]" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
 
