@@ -259,10 +259,11 @@ def test_full_c2_batch_properties(oracle_mod):
         m = blk.double().mean(dim=(1, 2))
         s = blk.double().flatten(1).std(dim=1, unbiased=True)
         assert m.abs().max() < 1e-5 and (s - 1).abs().max() < 1e-5
-    idx = [0, 1, 511, 777, 1023]
+    # a seeded random sample of 64 of the 1024 windows (plus the first and the last) against the oracle on every host core
+    idx = sorted(set([0, 1023] + np.random.default_rng(20260930).choice(1024, size=64, replace=False).tolist()))
     sub = tf.batch(Xd[idx])                                         # batch independence
     assert torch.equal(sub, a[idx])
-    ref, hd = oracle_mod.features(X[idx], 1000, KAISER, BAND, "stack", nthreads=5, return_halfdist=True)
+    ref, hd = oracle_mod.features(X[idx], 1000, KAISER, BAND, "stack", nthreads=min(len(idx), os.cpu_count() or 1), return_halfdist=True)
     an = a[idx].cpu().numpy()
     for i in range(len(idx)):
         parity.check(an[i], ref[i], hd[i], 0, what=f"c2[{idx[i]}]")
