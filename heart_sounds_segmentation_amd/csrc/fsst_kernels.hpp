@@ -28,6 +28,15 @@
 //   * MFMA is deliberately unused: at fp32 the matrix pipe has no rate advantage and the only
 //     dense contraction (the folded first stage) is K <= 16 deep.
 #pragma once
+// Development hooks (phase ablations, clock probes, alternative tilings: -DHSS_ABLATE, -DHSS_CANON_ABLATE, -DHSS_T16_ABLATE, -DHSS_*_PROBE,
+// -DHSS_NO_TIES, -DHSS_NO_EXACT, -DHSS_T16_NO_LAGPRIO, -DHSS_DEV_ONLY128 ...) change results or timing and exist for tools/ only: a build
+// that carries one must say so with -DHSS_DEV (tools/dev.sh does); the library that ships is compiled without any of them.
+#if !defined(HSS_DEV) && (defined(HSS_ABLATE) || defined(HSS_CANON_ABLATE) || defined(HSS_T16_ABLATE) || defined(HSS_FUSE_PROBE) || \
+                          defined(HSS_STREAM_PROBE) || defined(HSS_CLOCKPROBE) || defined(HSS_CANON_PROBE) || defined(HSS_NO_TIES) || \
+                          defined(HSS_NO_EXACT) || defined(HSS_T16_NO_LAGPRIO) || defined(HSS_DEV_ONLY128) || defined(HSS_TAIL_ENV) || \
+                          defined(HSS_LDS_PAD) || defined(HSS_WPB_CANON))
+#error "development hook without -DHSS_DEV: the shipped library carries none (tools/dev.sh builds development libraries)"
+#endif
 #include <hip/hip_runtime.h>
 
 #include <utility>

@@ -881,16 +881,6 @@ int hssfsst_dev_fuse_probe(unsigned long long* out8)
 }
 #endif
 
-#if defined(HSS_T16_PROBE) || defined(HSS_T16_WAITS)
-int hssfsst_dev_t16_probe(unsigned long long* out16)
-{
-    unsigned long long z[16] = {0};
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hssfsst::g_t16_probe), sizeof(z)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_probe), z, sizeof(z)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
 #ifdef HSS_STREAM_PROBE
 int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nwaves][8] of the last launch; cleared
 {
@@ -899,16 +889,6 @@ int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nw
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_stream_probe), sizeof(unsigned long long) * 8 * nwaves) != hipSuccess) return -1;
     std::vector<unsigned long long> z(static_cast<size_t>(hssfsst::kStreamProbeWaves) * 8, 0ull);
     if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_stream_probe), z.data(), z.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
-#ifdef HSS_T16_DEBUG
-int hssfsst_dev_t16_dbg(unsigned* out64)
-{
-    unsigned z[128] = {0};
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(hssfsst::g_t16_dbg), sizeof(z)) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_dbg), z, sizeof(z)) != hipSuccess) return -1;
     return 0;
 }
 #endif

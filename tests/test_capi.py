@@ -25,6 +25,19 @@ def test_every_declared_symbol_is_exported(built_lib):
     assert built_lib.hssfsst_version() == int(re.search(r"#define HSSFSST_VERSION (\d+)", text).group(1))
 
 
+def test_exported_symbols_are_exactly_the_header(built_lib):
+    """The shipped library exports the C ABI of include/hssfsst.h and nothing else under that prefix: no development entry
+    points (hssfsst_dev_*: they exist only in -DHSS_DEV builds, tools/dev.sh)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    r = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exported = sorted({ln.split()[-1] for ln in r.stdout.splitlines() if " T " in ln and ln.split()[-1].startswith("hssfsst")})
+    declared = sorted(set(re.findall(r"\b(hssfsst_[a-z_0-9]+)\s*\(", open(HEADER).read())))
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+
+
 def test_gfx950_code_object_present(built_lib):
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"fsst_core_kernel" in blob

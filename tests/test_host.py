@@ -228,3 +228,49 @@ def test_pack_recordings_equals_python_framing(built_lib):
                                              stage.numel() - 1, vp(starts.data_ptr()), starts.numel(), 1) < 0
     assert built_lib.hssfsst_pack_recordings(vp(ptrs.ctypes.data), vp(lens.ctypes.data), len(recs), 1000, 2000, vp(stage.data_ptr()),
                                              stage.numel(), vp(starts.data_ptr()), 10, 1) < 0
+
+
+def test_team_kernel_fixed_registers_are_nobodys_else(tmp_path):
+    """fsst_team16_kernel keeps its held images in v104..v127 through inline assembly and tells the register allocator to stay
+    below (amdgpu_num_vgpr: fsst_team16.hpp).  Checked on the listing: inside the team kernels the only instructions that name
+    a register >= v104 are the two accessors (v_pk_mul_f32 into a pair, v_pk_add_f32 out of one), and the code objects reserve
+    128 registers.  (A compiler that stopped honouring the limit would silently corrupt features.)"""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import pytest
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "dev.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DHSS_DEV", "-DHSS_DEV_ONLY128", "--cuda-device-only", "-S",
+                        "-o", str(out), os.path.join(root, "heart_sounds_segmentation_amd", "csrc", "hssfsst.hip")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text().split("\n")
+    starts = [i for i, ln in enumerate(text) if re.match(r"^_ZN7hssfsst18fsst_team16_kernel.*:", ln)]
+    assert len(starts) >= 2, "team kernels not found in the listing"
+    put = re.compile(r"^\s*v_pk_mul_f32 v\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\]\s*$")
+    get = re.compile(r"^\s*v_pk_add_f32 v\[\d+:\d+\], v\[(\d+):(\d+)\], v\[\d+:\d+\] op_sel")
+    for st in starts:
+        seen = set()
+        for ln in text[st:]:
+            if ln.startswith(".Lfunc_end"):
+                break
+            code = ln.split(";")[0]
+            regs = [int(a) for a in re.findall(r"\bv(\d+)\b", code)] + [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
+            if not regs or max(regs) < 104:
+                continue
+            m = put.match(code) or get.match(code)
+            assert m and int(m.group(1)) >= 104 and int(m.group(2)) == int(m.group(1)) + 1, f"register >= v104 outside the accessors: {ln.strip()}"
+            others = [int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
+            assert sum(1 for b in others if b >= 104) == 1, ln
+            seen.add(int(m.group(1)))
+        assert seen == set(range(104, 128, 2)), sorted(seen)
+    names = [i for i, ln in enumerate(text) if ".amdhsa_kernel _ZN7hssfsst18fsst_team16_kernel" in ln]
+    assert len(names) >= 2
+    for i in names:
+        blk = "\n".join(text[i:i + 60])
+        assert re.search(r"\.amdhsa_next_free_vgpr 128\b", blk), blk[:400]
