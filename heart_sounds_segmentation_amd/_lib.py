@@ -124,6 +124,8 @@ def lib():
         L.hssfsst_plan_last_exec_fused.argtypes = [vp]
         L.hssfsst_plan_set_zpath.argtypes = [vp, c_int]
         L.hssfsst_plan_fallbacks.argtypes = [vp]
+        L.hssfsst_allgather.argtypes = [vp, vp, c_i64, vp, vp, c_int]
+        L.hssfsst_allgather.restype = c_int
         L.hssfsst_plan_last_kernel.argtypes = [vp, ctypes.c_char_p, c_int]
         L.hssfsst_plan_last_kernel.restype = c_int
         L.hssfsst_plan_fallbacks.restype = c_int

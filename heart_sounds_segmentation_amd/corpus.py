@@ -97,6 +97,15 @@ class CorpusBuilder:
         for ``keep_on_device`` else host)."""
         fsst, stride, frame_len, dev = self.fsst, self.stride, self.frame_len, self.dev
         recs: Sequence = recordings if isinstance(recordings, (list, tuple)) else list(recordings)
+        # argument errors are properties of the WHOLE call and are raised before the list is cut to this rank's shard: a rank that
+        # raised alone left the others waiting in the gather that follows
+        if dev.type == "cuda" and not (getattr(fsst, "stack", False) or getattr(fsst, "abs", False)):
+            # (the raw transform is complex64 (frames, K, n), frequency-major: not the time-major float32 arena this builder fills)
+            raise ValueError("CorpusBuilder.build: the transform must have stack=True or abs=True (time-major float32 features); "
+                             "for the raw complex transform call FSST.frames per group of recordings")
+        kept_all = [y is not None for x, y in recs if x.shape[0] >= frame_len]
+        if 0 < sum(kept_all) < len(kept_all):
+            raise ValueError("CorpusBuilder.build: some recordings carry labels and some do not; pass labels for all or for none")
         if world is not None and world > 1:
             lo, hi = hdist.shard_bounds(len(recs), int(world), int(rank or 0))
             recs = recs[lo:hi]
@@ -106,10 +115,8 @@ class CorpusBuilder:
         nfr_np = np.where(L_np <= 0, 1, L_np).astype(np.int64)
         nfr = [int(v) for v in nfr_np]
         total = int(nfr_np.sum())
-        with_y = sum(1 for _, y in recs if y is not None)
-        if 0 < with_y < len(recs):
-            raise ValueError("CorpusBuilder.build: some recordings carry labels and some do not; pass labels for all or for none")
-        have_labels = total > 0 and with_y == len(recs)
+        have_labels = total > 0 and len(kept_all) > 0 and all(kept_all)      # (the same answer on every rank, also on one without frames)
+        have_labels = have_labels and len(recs) > 0
         # groups of about `windows_per_launch` frames (a launch per recording -- 33 frames -- leaves the chip idle)
         groups: List[Tuple[int, int]] = []
         g0, acc = 0, 0
@@ -149,10 +156,6 @@ class CorpusBuilder:
             return FrameItems(feats, labels)
 
         plan = fsst._plan(fsst._device_index(torch.empty(0, device=dev)))
-        if not (getattr(fsst, "stack", False) or getattr(fsst, "abs", False)):
-            # (the raw transform is complex64 (frames, K, n), frequency-major: not the time-major float32 arena this builder fills)
-            raise ValueError("CorpusBuilder.build: the transform must have stack=True or abs=True (time-major float32 features); "
-                             "for the raw complex transform call FSST.frames per group of recordings")
         C = plan.ofps
         shape = (total, frame_len, C)
         if out is not None and (tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous()

@@ -893,12 +893,16 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
             if (lane == 0) __hip_atomic_store(pw + role, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // (bounded like every wait of this library: the partner is a wave of the same workgroup and cannot stay away, but a
             //  kernel that could spin for ever is a kernel that can hang a GPU)
+            bool met = false;
             for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
                 int v = 0;
                 if (lane == 0) v = __hip_atomic_load(pw + (role ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__builtin_amdgcn_readfirstlane(v) - pphase >= 0) break;
+                if (__builtin_amdgcn_readfirstlane(v) - pphase >= 0) { met = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            // (a wait that ran out: the wave goes on -- on planes its partner may still be writing -- but not silently: the status word
+            //  makes hssfsst_plan_check / the next exec / the next streaming step fail, as the bounded waits of the other kernels do)
+            if (!met && lane == 0 && p.status) __hip_atomic_store((gu32*)(p.status), 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             wave_sync();
         }
     };
@@ -1309,12 +1313,14 @@ __global__ __launch_bounds__(64 * WPB, (NT == 32 ? 2 : WPB == 16 ? HSS_MW128 : W
             } else {
                 // (a list overflowed earlier: the odd wave forms its sources once the even wave is through its pass -- it has arrived
                 //  at the sync behind it --, adding into the plane itself: the same order)
+                bool met = false;
                 for (unsigned spins = 0; spins < kPairSpinLimit; ++spins) {
                     int v = 0;
                     if (lane == 0) v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) break;
+                    if (__builtin_amdgcn_readfirstlane(v) - (pphase + 1) >= 0) { met = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (!met && lane == 0 && p.status) __hip_atomic_store((gu32*)(p.status), 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 wave_sync();
                 if (lane == 0) pw[3] = 0;
             }

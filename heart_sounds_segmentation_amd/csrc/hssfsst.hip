@@ -11,6 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <mutex>
+#include <dlfcn.h>
 #include <cctype>
 #include <string>
 #include <atomic>
@@ -333,6 +336,7 @@ inline size_t core128_lds_bytes(const hssfsst_plan* pl, int rq, int nt, int wpb,
             (static_cast<size_t>(hssfsst::wave_lds_floats(kFpw128, pl->klo, pl->K, rq, nt)) + (pair ? hssfsst::kPairFloats : 0))) * sizeof(float);
 }
 
+int ensure_status(hssfsst_plan* pl);
 template <int NT, int RQ, bool FAST, int WPB, int S1C = -1, bool PAIR = false>
 int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t nchunks, hipStream_t st)
 {
@@ -354,6 +358,12 @@ int launch_core128_wpb(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     int64_t blocks = nchunks;                            // small launches: one chunk per block, spread over the CUs
     if (blocks > pl->core128_slots) blocks = pl->core128_slots;
     name_kernel(pl, WPB, blocks, "fsst_core128_kernel<%d, %d, %d, %s, %d, %d, false%s>", NT, RQ, kFpw128, FAST ? "true" : "false", WPB, S1C, PAIR ? ", pairs" : "");
+    if constexpr (PAIR) {                                // (a pair's bounded wait reports through the status word)
+        if (int rcs = ensure_status(pl)) return rcs;
+        hssfsst::Core128Params cq = cp;
+        cq.status = pl->d_status;
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, cq);
+    } else
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(64 * WPB), lds, st, cp);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1256,6 +1266,65 @@ int hssfsst_plan_last_kernel(const hssfsst_plan* p, char* buf, int len)
     return 0;
 }
 
+// ---- hssfsst_allgather: ncclAllGather through dlopen (no link-time dependency on RCCL)
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi& rccl_api()
+{
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!api.tried) {
+        api.tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(api.handle, "ncclAllGather"));
+            api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(api.handle, "ncclGetErrorString"));
+        }
+    }
+    return api;
+}
+}  // namespace
+
+int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void* nccl_comm, void* stream, int timeout_ms)
+{
+    if (!sendbuf || !recvbuf || !nccl_comm || count < 0 || timeout_ms < 0) return fail(HSSFSST_EINVAL, "allgather: bad argument");
+    if (count == 0) return 0;
+    RcclApi& api = rccl_api();
+    if (!api.all_gather) return fail(HSSFSST_EUNSUPPORTED, "allgather: RCCL (librccl.so.1: ncclAllGather) is not available: %s", api.handle ? "symbol missing" : dlerror());
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    constexpr int kNcclFloat32 = 7;                      // ncclFloat (rccl.h)
+    const int rc = api.all_gather(sendbuf, recvbuf, static_cast<size_t>(count), kNcclFloat32, nccl_comm, st);
+    if (rc != 0) return fail(HSSFSST_EHIP, "allgather: ncclAllGather: %s", api.error_string ? api.error_string(rc) : "error");
+    if (timeout_ms == 0) return 0;
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, st);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (e == hipSuccess) {
+        e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) break;
+        e = hipSuccess;
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
+            (void)hipEventDestroy(ev);
+            return fail(HSSFSST_EHIP, "allgather: the collective did not complete within %d ms (a rank is missing?)", timeout_ms);
+        }
+        std::this_thread::yield();
+    }
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(HSSFSST_EHIP, "allgather: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int hssfsst_plan_fallbacks(hssfsst_plan* p)
 {
     if (!p) return fail(HSSFSST_EINVAL, "plan_fallbacks: plan is NULL");
@@ -1773,6 +1842,12 @@ int hssfsst_stream_step(hssfsst_plan* p, float* tape, int64_t tape_len, int64_t 
     if (p->h_status && *p->h_status != 0u) {             // an earlier step's wait between blocks gave up (see hssfsst_plan_check)
         const unsigned code = *p->h_status;
         *p->h_status = 0u;
+        // (a step that gave up may have left its channels' arrival counters short of a full round: later steps would never
+        //  normalise -- start them from zero again)
+        if (p->d_stream_arrive && p->stream_arrive_cap > 0) {
+            DEVICE_SCOPE(p->device);
+            (void)hipMemsetAsync(p->d_stream_arrive, 0, static_cast<size_t>(p->stream_arrive_cap) * sizeof(unsigned), static_cast<hipStream_t>(stream));
+        }
         return fail(HSSFSST_EHIP, "stream_step: an earlier step gave up waiting inside its launch (code %u); its output is invalid", code);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -10,12 +10,15 @@ is testable on CPU with the gloo backend (tests/test_dist.py).
 Where the exchange runs: RCCL moves device memory only, so under the ``nccl`` backend every tensor handed to a
 collective lives on this process's current GPU (host features are staged there first and the result stays there unless
 ``out_device`` says otherwise); under ``gloo`` the tensors stay where they are.  Ragged blocks (the recording-level
-corpus split: a rank's window count depends on its recordings' lengths) are gathered STRAIGHT into the final buffer by ONE
-collective over per-rank views of it (RCCL's all_gather takes unequal blocks) -- no padded copy, no concatenation; a rank that
-holds no rows takes part with an empty block.  (gloo, which the CPU tests and the one-GPU dry run use, wants equal blocks: one
-padded all-gather and a compaction.)
+corpus split: a rank's window count depends on its recordings' lengths) are gathered by ONE ``all_gather_into_tensor`` of blocks
+padded to the largest count plus a compaction pass -- under RCCL and gloo alike: it is the one collective every N-rank RCCL job
+exercises, and this code has never run on more than one GPU (no multi-GPU node in rounds 1-5); a rank that holds no rows takes
+part with a block of padding.  ``HSSFSST_DIST_UNEVEN=1`` opts into a single ``dist.all_gather`` over unequal per-rank views of the
+result instead (no staging buffer; untested on hardware, never used for empty blocks).
 """
 from __future__ import annotations
+
+import os
 
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -133,14 +136,18 @@ def _gather_counts(local: torch.Tensor, counts: Sequence[int], tail: Tuple[int, 
         dist.all_gather_into_tensor(out, mine if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() else mine.clone(),
                                     group=group)
         return out
-    if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower():
-        # ONE collective over per-rank views of the result: RCCL's all_gather takes unequal blocks (a grouped set of direct
-        # sends, every block crossing every xGMI link once) -- no padding, no concatenation, and not one ring broadcast per rank
+    if (dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() and min(counts) > 0
+            and os.environ.get("HSSFSST_DIST_UNEVEN", "0") == "1"):
+        # OPT-IN (HSSFSST_DIST_UNEVEN=1): one dist.all_gather over per-rank views of the result.  torch lowers unequal blocks under
+        # NCCL / RCCL to a coalesced group of per-rank broadcasts (ProcessGroupNCCL::allgather, as recalled -- not checked against this
+        # build); it has NEVER run here with more than one rank (no multi-GPU node in rounds 1-5), and whether RCCL takes empty blocks is
+        # unknown, so blocks without rows never come this way.  The default below uses only all_gather_into_tensor of equal blocks --
+        # the collective every N-rank RCCL job exercises -- at the price of a padded staging buffer and one compaction pass.
         views = [out[offs[r]: offs[r + 1]] for r in range(world)]
         dist.all_gather(views, mine, group=group)
         return out
-    # gloo (the CPU tests and the one-GPU dry run) insists on equal blocks: ONE all_gather_into_tensor of blocks padded to the
-    # largest count, then the valid rows of every block into place
+    # ragged blocks (RCCL by default, gloo always -- gloo insists on equal blocks): ONE all_gather_into_tensor of blocks padded to the
+    # largest count, then the valid rows of every block into place; a rank without rows takes part with a block of padding
     cmax = max(counts)
     stage = torch.zeros((world, cmax) + tuple(tail), dtype=local.dtype, device=dev)
     pad = torch.zeros((cmax,) + tuple(tail), dtype=local.dtype, device=dev)

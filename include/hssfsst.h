@@ -136,6 +136,15 @@ int hssfsst_plan_set_zpath(hssfsst_plan* plan, int zpath);
  * synchronisation).  (Signals that ride on an offset no longer count here: since round 5 the team kernel computes them itself.) */
 int hssfsst_plan_fallbacks(hssfsst_plan* plan);
 
+/* Multi-GPU reassembly of the feature batch -- the one exchange of the path (BASELINE north_star: "an RCCL all-gather over xGMI only
+ * to reassemble the feature batch for the LSTM"; the reference itself has no distributed code, main.py:224-230) -- without torch:
+ * every rank contributes `count` floats at sendbuf and receives world x count floats, in rank order, at recvbuf (device pointers;
+ * sendbuf may be recvbuf + rank x count: in place).  comm: the caller's ncclComm_t (one process per GPU).  RCCL is loaded with
+ * dlopen("librccl.so.1") on first use: the library does not link it, and a host without it gets HSSFSST_EUNSUPPORTED here only.
+ * timeout_ms > 0: the call waits for the collective on `stream`, at most that long (HSSFSST_EHIP when exceeded: a peer is missing
+ * -- every wait of this library is bounded); 0: returns after enqueueing. */
+int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void* nccl_comm, void* stream, int timeout_ms);
+
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
  * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the

@@ -219,5 +219,50 @@ def test_bench_n_ranks_dry_run_over_gloo(world):
     assert d["config"]["windows_per_gpu"] == 32 and "dry_run" in d["config"]
     assert "error" not in d.get("allgather", {}) and d["allgather"]["bytes_per_rank"] == 32 * 2000 * 44 * 4
     c3 = d["c3"]
-    assert "error" not in c3 and c3["n_gpus"] if "n_gpus" in c3 else True
+    assert "error" not in c3, c3
+    if "n_gpus" in c3:
+        assert c3["n_gpus"] == world
     assert c3["allgather"]["shape_ok"] is True and "error" not in c3["allgather"]
+
+
+@pytest.mark.gpu
+def test_c_abi_allgather_one_rank_rccl():
+    """hssfsst_allgather: the torch-free form of the path's one exchange -- ncclAllGather through the library,
+    RCCL loaded with dlopen.  One rank (the only world a one-GPU box has): the communicator is made here with RCCL's own C API,
+    the gather runs out of place and in place, a bounded wait returns.  (More than one rank has never run: no multi-GPU node.)"""
+    import ctypes
+    import torch
+    from heart_sounds_segmentation_amd import _lib
+    try:
+        R = ctypes.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("no librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    R.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    R.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    R.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    torch.cuda.init()
+    torch.zeros(1, device="cuda")
+    uid = UniqueId()
+    assert R.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert R.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        L = _lib.lib()
+        src = torch.arange(3 * 2000 * 44, dtype=torch.float32, device="cuda")
+        dst = torch.zeros_like(src)
+        st = torch.cuda.current_stream().cuda_stream
+        rc = L.hssfsst_allgather(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel(), comm, ctypes.c_void_p(st), 5000)
+        assert rc == 0, L.hssfsst_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst)
+        dst.mul_(2.0)                                    # in place: the rank's block is its own slot of the result
+        rc = L.hssfsst_allgather(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(dst.data_ptr()), dst.numel(), comm, ctypes.c_void_p(st), 0)
+        assert rc == 0, L.hssfsst_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src * 2.0)
+        assert L.hssfsst_allgather(None, ctypes.c_void_p(dst.data_ptr()), 4, comm, None, 0) != 0      # bad argument: status, no throw
+    finally:
+        R.ncclCommDestroy(comm)
