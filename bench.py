@@ -47,32 +47,44 @@ def csrc_digest():
 
 def pmc_profile(kernel_substr):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command
-    (profiles/r04_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
-    MI355X guide prescribes).  None when the file is absent or was measured on other sources."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc.json")
-    try:
-        with open(path) as fh:
-            prof = json.load(fh)
-        if prof.get("csrc_sha256") != csrc_digest():
-            return None
-        for name, v in prof["kernels"].items():
-            if kernel_substr in name:
-                return v
-    except (OSError, KeyError, ValueError):
-        pass
+    (profiles/rNN_pmc.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE corrected as the
+    MI355X guide prescribes): the newest round's file whose SHA-256 of csrc/ matches the sources in the tree.  None when
+    there is none -- never figures measured on other sources."""
+    import glob
+    digest = csrc_digest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                prof = json.load(fh)
+            if prof.get("csrc_sha256") != digest:
+                continue
+            for name, v in prof["kernels"].items():
+                if kernel_substr in name:
+                    return dict(v, _file=os.path.relpath(path, ROOT))
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
 def census_max_rel_err():
-    """Largest per-column error of the canonical kernels against the float64 oracle over the committed 2 M-column census
-    (profiles/r04_split_fold_census.txt, tools/split_fold_census.py): what the 22-bit operands of the fold amount to."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_split_fold_census.txt")) as fh:
-            for ln in fh:
-                if ln.startswith("arithmetic_max_rel_err"):
-                    return float(ln.split()[1])
-    except (OSError, ValueError):
-        pass
+    """Largest per-column error of the canonical kernels against the float64 oracle over a committed 2 M-column census
+    (profiles/rNN_split_fold_census.txt, tools/split_fold_census.py): what the 22-bit operands of the fold amount to.
+    A COMMITTED figure: (value, file, whether the file names the sources in the tree)."""
+    import glob
+    digest = csrc_digest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_split_fold_census.txt")), reverse=True):
+        try:
+            val, sha = None, None
+            with open(path) as fh:
+                for ln in fh:
+                    if ln.startswith("arithmetic_max_rel_err"):
+                        val = float(ln.split()[1])
+                    if ln.startswith("csrc_sha256"):
+                        sha = ln.split()[1]
+            if val is not None:
+                return {"value": val, "source": os.path.relpath(path, ROOT), "same_sources": bool(sha == digest)}
+        except (OSError, ValueError):
+            pass
     return None
 
 
@@ -222,6 +234,44 @@ def bench_c5(steps, warmup):
                          "unit": "GB/s", "frac": round((ch * chunk * 4 + ch * chunk * 44 * 4) / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                          "note": "latency bound: 1.47 MB per step, one 16-frame group per pair of waves"}}
     return line
+
+
+def bench_c1(tf, calls=400):
+    """BASELINE config 1 through the UNCHANGED dataset loop: the transform called once per 2000-sample frame with a CPU tensor and
+    returning a CPU tensor (/root/reference/hss/datasets/heart_sounds.py:166-168,199-201) -- one window per call, host to host,
+    PCIe and Python included -- and the 33 frames of one 35 500-sample recording that way (hss/utils/preprocess.py:40-52)."""
+    import numpy as np
+    import torch
+
+    from heart_sounds_segmentation_amd import synth
+    from heart_sounds_segmentation_amd.framing import frame_batch
+    fr = torch.from_numpy(synth.pcg_windows(1, 2000, seed=77)[0]).reshape(2000, 1)
+    for _ in range(50):
+        tf(fr)
+    lat = []
+    for _ in range(calls):
+        t1 = time.perf_counter()
+        y = tf(fr)
+        lat.append(time.perf_counter() - t1)
+    lat = np.sort(np.asarray(lat)) * 1e3
+    rec = torch.from_numpy(synth.recording(35500, seed=78))
+    frames = frame_batch(rec, 1000, 2000)                    # the reference's 33 frames
+    for _ in range(3):
+        for f in frames:
+            tf(f.reshape(2000, 1))
+    t1 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        feats = [tf(f.reshape(2000, 1)) for f in frames]
+    rec_ms = (time.perf_counter() - t1) / reps * 1e3
+    return {"metric": "drop-in FSST.__call__, one 2000-sample CPU frame per call (the reference's dataset loop)",
+            "value": round(1e3 / float(np.median(lat)), 1), "unit": "windows/s per process",
+            "ms_per_call": {"median": round(float(np.median(lat)), 4), "min": round(float(lat[0]), 4), "p99": round(float(lat[int(0.99 * (len(lat) - 1))]), 4)},
+            "recording_35500_samples": {"frames": int(frames.shape[0]), "ms": round(rec_ms, 3),
+                                        "out_shape": [int(v) for v in feats[0].shape]},
+            "path": "CPU float32 (2000, 1) tensor -> pinned mapped staging read by the kernel -> team kernel -> features stored to pinned host "
+                    "memory by the kernel -> stream sync -> copy into the returned CPU tensor (PCIe, Python and the synchronisation included)",
+            "kernel": tf.last_kernel()}
 
 
 def bench_c3(dev, rank, world, use_dist, steps, warmup, nrec=792, T=35500, host_fed=True):
@@ -424,12 +474,21 @@ def main():
     for _ in range(untimed):
         tf.batch(X, out=out)
     sync_all()
-    tf.set_timing(True, local)
+    # Events are packets on the exec stream: the library's pair around the kernel of EVERY step plus a marker per step cost ~8 us of a
+    # 0.19 ms step (measured: profiles/r05_team_diet.txt).  So the dominant kernel is timed on 5-10 of the K steps (its duration does not
+    # depend on which), and the spread of the steps comes from as many markers; the timed region itself is still the K steps between the barriers.
+    every = max(1, args.steps // (10 if args.steps >= 100 else 5))
+    tf.set_timing(every, local)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // every + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         tf.batch(X, out=out)
+        if (i + 1) % every == 0:
+            marks[(i + 1) // every].record()
     sync_all()
     elapsed = time.perf_counter() - t0
+    seg_ms = sorted(marks[i].elapsed_time(marks[i + 1]) / every for i in range(args.steps // every)) if args.steps >= every else []
     core_ms, norm_ms, ncalls = tf.timing(local)
     tf.set_timing(False, local)
     fused = tf.check(local)                                   # raises if a kernel reported a failed internal wait
@@ -479,11 +538,24 @@ def main():
         roof = {"bound": "hbm", "kernel": kname + kdesc, "launch": klong,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_source": (live["how"] if live else ("profiles/r04_pmc.json (same sources, SHA-256 checked)" if prof else None)),
+                "traffic_source": (live["how"] if live else (prof["_file"] + " (same sources, SHA-256 checked)" if prof else None)),
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom_ms, 4),
-                "other_kernels_avg_ms": round(norm_ms / max(ncalls, 1), 4), "launches_timed": ncalls,
+                # everything of a step that is not the dominant kernel: the library's own events (z-score kernels of the two-launch
+                # path) and -- wall clock minus kernel -- the gated fallback launch queued behind every team launch (~4 us) and gaps
+                "other_kernels_avg_ms": round(max(norm_ms / max(ncalls, 1), ms_per_step - dom_ms, 0.0), 4), "launches_timed": ncalls,
+                "launches_timed_of": args.steps,
+                "step_ms_spread": ({"min": round(seg_ms[0], 4), "median": round(seg_ms[len(seg_ms) // 2], 4), "max": round(seg_ms[-1], 4),
+                                    "samples": len(seg_ms), "steps_per_sample": every,
+                                    "how": "HIP events on the exec stream inside the timed region, one per steps_per_sample steps"} if seg_ms else None),
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
                 "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / HBM_PEAK_GBS, 5)}
+        if prof and all(k in prof for k in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES")) and prof["SQ_WAVE_CYCLES"] > 0:
+            # the bound that actually binds: issue slots.  A wave64 VALU instruction holds its SIMD for 4 clocks, a
+            # v_mfma_f32_16x16x32_f16 for 16 (they do not overlap: profiles/r01_mfma_valu_overlap_ubench.txt); SQ_WAVE_CYCLES counts 4-clock
+            # units per wave and four waves share a SIMD for the whole launch, so it is also the launch's SIMD-clocks summed over SIMDs
+            roof["issue_frac"] = round((4.0 * prof["SQ_INSTS_VALU"] + 16.0 * prof["SQ_INSTS_MFMA"]) / prof["SQ_WAVE_CYCLES"], 4)
+            roof["issue_note"] = ("(4 x VALU + 16 x MFMA wave-instructions) / SIMD-clocks of the launch, from " + prof["_file"] +
+                                  ": the kernel is issue-bound, this is the fraction that can reach 1.0; `frac` (HBM) stays the headline")
         if prof and "SQ_INSTS_MFMA" in prof and "SQ_INSTS_VALU" in prof and dom_ms > 0:
             canon = "canon" in kname or "4, 22" in kname
             flop = (0 if canon else prof["SQ_INSTS_MFMA"] * MFMA_FLOP) + prof["SQ_INSTS_VALU"] * 64 * VALU_FLOP_PER_LANE
@@ -493,11 +565,11 @@ def main():
                 roof["mfma_f16_tflops"] = round(prof["SQ_INSTS_MFMA"] * MFMA_F16_FLOP / (dom_ms * 1e-3) / 1e12, 2)
                 roof["fp32_note"] = (f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) per launch, "
                                      f"peak {FP32_PEAK_TFLOPS} TFLOP/s; besides {int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x32_f16 x {MFMA_F16_FLOP} FLOP "
-                                     "(the window fold with split operands: 4 half products per real one) on the 16-bit matrix pipe (profiles/r04_pmc.json)")
+                                     "(the window fold with split operands: 4 half products per real one) on the 16-bit matrix pipe (" + prof["_file"] + ")")
             else:
                 roof["fp32_note"] = (f"{int(prof['SQ_INSTS_MFMA'])} v_mfma_f32_16x16x4_f32 x {MFMA_FLOP} FLOP + "
                                      f"{int(prof['SQ_INSTS_VALU'])} VALU wave-instructions x 64 lanes x {VALU_FLOP_PER_LANE} FLOP (estimate) "
-                                     f"per launch (profiles/r04_pmc.json); peak {FP32_PEAK_TFLOPS} TFLOP/s")
+                                     f"per launch ({prof['_file']}); peak {FP32_PEAK_TFLOPS} TFLOP/s")
         # the same workload on the other single-launch kernel (one CU per signal: the tile round-trips through HBM), beside the default
         if world == 1 and not args.no_extras and fused == 2 and not os.environ.get("HSSFSST_NO_CANON"):
             try:
@@ -552,6 +624,11 @@ def main():
     # the other BASELINE configurations of the path, carried by the same line: C3 (corpus preprocessing, recording-level
     # split, RCCL all-gather when N > 1) on every N, C5 (streaming) on one GPU
     extras = {}
+    if not args.no_extras and world == 1:
+        try:
+            extras["c1"] = bench_c1(tf)
+        except Exception as e:                                   # never lose the bench line to a side measurement
+            extras["c1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_extras:
         del out
         try:

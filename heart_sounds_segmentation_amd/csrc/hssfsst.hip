@@ -265,7 +265,9 @@ struct hssfsst_plan {
     unsigned deferred_launch = 0, deferred_first = 0;        // the host looks at the pinned give-up word afterwards and redoes the exec itself
     long long* d_starts = nullptr; size_t starts_cap = 0;    // frame-list staging (hssfsst_exec_list with host starts)
     float* d_frames = nullptr;    size_t frames_cap = 0;     // frames gathered from a list, dense [batch][n]
-    int timing = 0;
+    int timing = 0;               // the exec being queued records kernel events
+    int timing_every = 0;         // hssfsst_plan_set_timing(n): every n-th exec is timed (0: off)
+    unsigned timing_seq = 0;
     bool timing_closed = false;   // the exec being queued has already recorded its closing kernel event (team path: right behind the team kernel)
     std::vector<hipEvent_t> ev;   // per timed exec: (before, after) per core launch + one closing event
     size_t ev_used = 0;           // events used since timing was enabled
@@ -788,7 +790,11 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
                     HIP_TRY(hipEventRecord(evt, st));
                     pl->timing_closed = true;
                 }
+#ifdef HSS_NO_GATE                                        // development: what the gated launch behind every team launch costs (UNSAFE: no fallback)
+                if (true) {
+#else
                 if (pl->defer_fallback) {                // (exec_impl: a host-output exec synchronises anyway and checks the give-up word then)
+#endif
                     if (pl->deferred_launch == 0u) pl->deferred_first = pl->team_launch;
                     pl->deferred_launch = pl->team_launch;
                     *did_fuse = true;
@@ -1359,7 +1365,9 @@ int hssfsst_plan_check(hssfsst_plan* p)
 int hssfsst_plan_set_timing(hssfsst_plan* p, int enable)
 {
     if (!p) return fail(HSSFSST_EINVAL, "plan_set_timing: plan is NULL");
-    p->timing = enable ? 1 : 0;
+    p->timing_every = enable > 0 ? enable : 0;
+    p->timing = 0;
+    p->timing_seq = 0;
     p->ev_used = 0;
     p->ev_chunks.clear();
     return 0;
@@ -1504,6 +1512,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     auto next_event = [&](hipEvent_t* out_ev) -> int { return plan_next_event(p, out_ev); };
     int timed_chunks = 0;
     p->timing_closed = false;
+    p->timing = (p->timing_every > 0 && (p->timing_seq++ % static_cast<unsigned>(p->timing_every)) == 0u) ? 1 : 0;
     // STACK: core (FP32-issue-bound) then the z-score sweep (HBM-bound, in place).  An optional
     // pipeline (HSSFSST_CHUNKS=k) cuts the batch into k chunks and runs the sweep of chunk i on a side
     // stream while the core of chunk i+1 runs on the caller's stream.  Measured on MI355X

@@ -305,10 +305,11 @@ class FSST:
         dev = self._device_index() if device_index is None else device_index
         return int(_lib.lib().hssfsst_plan_fallbacks(self._plan(dev).handle))
 
-    def set_timing(self, enable: bool, device_index: Optional[int] = None) -> None:
-        """Extension (bench): record HIP events around the kernels of every following call."""
+    def set_timing(self, enable, device_index: Optional[int] = None) -> None:
+        """Extension (bench): record HIP events around the kernels of every following call (``True`` / 1) or of every n-th one
+        (an int n > 1: the events themselves cost stream time); ``False`` / 0: off."""
         dev = self._device_index() if device_index is None else device_index
-        _lib.check(_lib.lib().hssfsst_plan_set_timing(self._plan(dev).handle, 1 if enable else 0),
+        _lib.check(_lib.lib().hssfsst_plan_set_timing(self._plan(dev).handle, int(enable)),
                    "hssfsst_plan_set_timing")
 
     def timing(self, device_index: Optional[int] = None):

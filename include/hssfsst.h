@@ -148,7 +148,8 @@ int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void*
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every
  * hssfsst_exec records events around each of its core-kernel launches (a STACK exec runs the batch in
  * cache-sized chunks: core, z-score, core, z-score ...) WITHOUT synchronising; enabling resets the
- * record.  hssfsst_plan_timing() synchronises once and returns, over all execs since enabling:
+ * record.  enable = n > 1 times every n-th exec only (an event is a packet on the stream: two per exec cost a
+ * 0.18 ms exec ~3 us).  hssfsst_plan_timing() synchronises once and returns, over all TIMED execs since enabling:
  * ms_sum[0] = total synchrosqueeze-core kernel time, ms_sum[1] = rest of the exec (z-score kernels,
  * 0 unless STACK), both in milliseconds, and *nexec = number of execs recorded. */
 int hssfsst_plan_set_timing(hssfsst_plan* plan, int enable);

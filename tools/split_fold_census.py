@@ -52,3 +52,5 @@ for label, env in (("canonical kernels (split-f16 fold, 22-bit operands)", {}), 
             print(f"{label:58s} {name:6s} columns {e_.size:8d}  max {e_.max():.3e}  99.99th pct {np.quantile(e_, 0.9999):.3e}  median {np.median(e_):.3e}  "
                   f"> 1e-6: {int((e_ > 1e-6).sum())}  > 1e-5: {int((e_ > 1e-5).sum())}  fragile {int((~robust).sum())} flipped {int((err[~robust] > parity.TOL).sum())}   [{kern}]", flush=True)
 print(f"arithmetic_max_rel_err {worst:.3e}")
+import bench as _bench
+print(f"csrc_sha256 {_bench.csrc_digest()}")

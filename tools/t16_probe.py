@@ -25,17 +25,20 @@ def main():
     X = torch.from_numpy((synth.pcg_windows(B, n) + float(os.environ.get("T16_OFFSET", "0"))).astype(np.float32)).cuda()
     out = torch.empty((B, n, 44), dtype=torch.float32, device="cuda")
     for rd in range(int(os.environ.get("T16_ROUNDS", "4"))):
-        L.hssfsst_plan_set_timing(plan, 1)
+        L.hssfsst_plan_set_timing(plan, 0 if os.environ.get("T16_NOTIMING") else 1)
+        torch.cuda.synchronize(); import time as _t; _w0 = _t.perf_counter()
         for _ in range(int(os.environ.get("T16_EXECS", "100"))):
             rc = L.hssfsst_exec(plan, ctypes.c_void_p(X.data_ptr()), B, n, 1, ctypes.c_void_p(out.data_ptr()), 1, None)
             assert rc == 0, L.hssfsst_last_error()
         ms = (ctypes.c_float * 2)(); cnt = ctypes.c_int()
         L.hssfsst_plan_timing(plan, ms, ctypes.byref(cnt))
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(); _wall = (_t.perf_counter() - _w0) / max(cnt.value, 1) * 1e3
         fb = L.hssfsst_plan_fallbacks(plan)
+        if cnt.value == 0:
+            torch.cuda.synchronize(); print(f"round {rd}: wall {(_t.perf_counter() - _w0) / int(os.environ.get('T16_EXECS', '100')) * 1e3:.4f} ms/exec (no events)", flush=True); continue
         t = (ms[0] + ms[1]) / cnt.value
         print(f"round {rd}: {B}x{n} {t:.4f} ms/exec (core {ms[0] / cnt.value:.4f})  {B / t / 1e3:.3f} Mwin/s  {(8000 + 352000) * (n / 2000) * B / (t * 1e-3) / 8e12 * 100:.2f}% of 8 TB/s  "
-              f"zpath={L.hssfsst_plan_last_exec_fused(plan)} fallbacks={fb}", flush=True)
+              f"zpath={L.hssfsst_plan_last_exec_fused(plan)} fallbacks={fb}  wall {_wall:.4f} ms/exec", flush=True)
         if hasattr(L, "hssfsst_dev_t16_probe"):
             buf = (ctypes.c_ulonglong * 16)()
             L.hssfsst_dev_t16_probe(buf)
