@@ -408,6 +408,61 @@ __device__ __forceinline__ float4 stats_finish_pre(double acc, double it, double
     return make_float4(static_cast<float>(mr), 1.0f / sqrtf(static_cast<float>(vr)),
                        static_cast<float>(mi), 1.0f / sqrtf(static_cast<float>(vi)));
 }
+// The same sums for a caller that needs them in ONE place only (fsst_team16_kernel's resolver: a wave at raised priority that fifteen
+// siblings wait for): a DIRECTED reduction towards lanes 0..3 instead of the butterfly -- at every level only the lower partner adds, so
+// lanes 0..3 receive exactly the additions the butterfly makes there (same operands, same order: the same bits), and the other lanes'
+// values are never read.  One exchange per 32-bit half and level instead of the butterfly's select between two candidates.
+__device__ __forceinline__ float4 stats_finish_lead(double acc, double it, double it1, int lane)
+{
+    auto halves = [](double v, unsigned& lo, unsigned& hi) {
+        const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+        lo = static_cast<unsigned>(b); hi = static_cast<unsigned>(b >> 32);
+    };
+    auto join = [](unsigned lo, unsigned hi) { return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo)); };
+    unsigned lo, hi;
+    {   // lane + 4 (within the 16-lane row): a rotation by 4 one way or the other -- which way is read off the lane ids, once
+        const int from = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_update_dpp(0, lane, 0x124, 0xf, 0xf, false));     // row_ror:4
+        halves(acc, lo, hi);
+        unsigned plo, phi;
+        if (from == 4) {
+            plo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), 0x124, 0xf, 0xf, false));
+            phi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), 0x124, 0xf, 0xf, false));
+        } else {
+            plo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), 0x12c, 0xf, 0xf, false));      // row_ror:12
+            phi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), 0x12c, 0xf, 0xf, false));
+        }
+        acc = acc + join(plo, phi);
+    }
+    {   // lane + 8: row_ror:8 either way
+        halves(acc, lo, hi);
+        const unsigned plo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), 0x128, 0xf, 0xf, false));
+        const unsigned phi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hi), 0x128, 0xf, 0xf, false));
+        acc = acc + join(plo, phi);
+    }
+    {   // lane + 16: the next row (v_permlane16_swap of a register with itself: the second result holds the odd rows in the even rows' place)
+        halves(acc, lo, hi);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        acc = acc + join(rl[1], rh[1]);
+    }
+    {   // lane + 32: the upper half (v_permlane32_swap: the second result holds the upper half in the lower half's place)
+        halves(acc, lo, hi);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        acc = acc + join(rl[1], rh[1]);
+    }
+    auto from_lane = [&](int l) {
+        const long long b = __double_as_longlong(acc);
+        const int l0 = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffll), l);
+        const int h0 = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), l);
+        return __longlong_as_double((static_cast<long long>(h0) << 32) | static_cast<unsigned>(l0));
+    };
+    const double sx_re = from_lane(0), sxx_re = from_lane(1), sx_im = from_lane(2), sxx_im = from_lane(3);
+    const double mr = sx_re * it, mi = sx_im * it;
+    const double vr = fma(-sx_re, mr, sxx_re) * it1, vi = fma(-sx_im, mi, sxx_im) * it1;
+    return make_float4(static_cast<float>(mr), 1.0f / sqrtf(static_cast<float>(vr)),
+                       static_cast<float>(mi), 1.0f / sqrtf(static_cast<float>(vi)));
+}
 __device__ __forceinline__ float4 stats_finish(double acc, double total, int lane)
 {
     return stats_finish_pre(acc, 1.0 / total, 1.0 / (total - 1.0), lane);

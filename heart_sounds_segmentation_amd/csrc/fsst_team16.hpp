@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         if (blk0 < nblocks) acc += sb[0];
         if (blk0 + 16 < nblocks) acc += sb[1];
         static_assert(kT16MaxBlocks <= 32, "a lane sums at most two blocks");
-        const float4 r = stats_finish_pre(acc, P()->inv_total, P()->inv_total1, lane_r);
+        const float4 r = stats_finish_lead(acc, P()->inv_total, P()->inv_total1, lane_r);
         if (lane == 0) {
             float4* f3 = fin + 3 * (ko & smask);
             f3[0] = make_float4(r.x, r.y, r.x, r.y);
