@@ -208,10 +208,12 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
 // rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
 // xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
 // the group's first output column, for the float64 tie path.
-template <int KLO, int KC, int TAPB = 4, bool OFFS = true>
+// (xsig: the signal's samples for the float64 rounding-tie path -- a pointer, or a callable that makes it: a kernel whose signal base is
+//  a 64-bit product per group hands over the recipe and pays for it in the rare path only)
+template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
-                                            const float* xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
+                                            XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
@@ -371,7 +373,9 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     asm volatile("" : "+v"(f_dirty), "+v"(f_ties));      // the compiler from sinking the second read behind the first branch)
     auto signal_sample = [&](int i) -> double {
         const int gi = tg + i - NWIN / 2;
-        return (gi >= 0 && gi < n) ? static_cast<double>(xsig[gi]) : 0.0;
+        const float* xs;
+        if constexpr (__is_pointer(XSig)) xs = xsig; else xs = xsig();
+        return (gi >= 0 && gi < n) ? static_cast<double>(xs[gi]) : 0.0;
     };
     bool exact = false;
 #ifndef HSS_NO_EXACT

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     constexpr int nwords = kT16MaxBlocks * kT16BlockWords;     // tagged words per signal in the mailbox
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * nwords;
     const int nblocks = (G + kStatBlock - 1) / kStatBlock;
-    const long long sig_bytes = static_cast<long long>(ncols) * (2 * K * 4);      // a signal's feature block
+    const unsigned sig_bytes = static_cast<unsigned>(ncols) * (2 * K * 4);         // a signal's feature block (at most 128 groups: 32 bits)
 
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         if (d_valid) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
-            const float* xsig = P()->x + (static_cast<long long>(team) + static_cast<long long>(ko_d) * nteams) * P()->xstride;
+            // (signal index and stride are 32-bit here -- the host sends nothing else to this kernel: a 32 x 32 -> 64-bit product, not 64 x 64)
+            const float* xsig = P()->x + static_cast<unsigned long long>(static_cast<unsigned>(team + ko_d * nteams)) * static_cast<unsigned>(P()->xstride);
             canon_fetch(xsig, n, ((g_d + cg0) & ~3) * 16, lane_o, sreg);
         }
     };
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const unsigned cofs = cls_lds[lane_r];
         const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_h & smask));
-        const long long b = static_cast<long long>(team) + static_cast<long long>(ko_h) * nteams;
-        char* obase = reinterpret_cast<char*>(P()->out) + b * sig_bytes + static_cast<long long>(g_h) * (16 * 2 * K * 4);       // (wave-uniform)
+        char* obase = reinterpret_cast<char*>(P()->out) + static_cast<unsigned long long>(static_cast<unsigned>(team + ko_h * nteams)) * sig_bytes +
+                      static_cast<unsigned>(g_h * (16 * 2 * K * 4));                                                          // (wave-uniform)
         const unsigned voff = static_cast<unsigned>(lane_r) * 16u;
         const int nvalid = min(16, ncols - g_h * 16);
         auto put = [&](auto I) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         }
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const long long b = static_cast<long long>(team) + static_cast<long long>(ko) * nteams;
+        const unsigned b = static_cast<unsigned>(team + ko * nteams);
         const int tg = P()->col0 + g * 16;
 #ifndef HSS_T16_NO_LAGPRIO
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         }
 #endif
         canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
-                                           P()->x + b * P()->xstride, n, tg, P()->atab + kCanonAtabFloats);
+                                           [&]() -> const float* { return P()->x + static_cast<unsigned long long>(b) * static_cast<unsigned>(P()->xstride); }, n, tg, P()->atab + kCanonAtabFloats);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
         c_valid = false;

@@ -573,6 +573,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     const int grid = (pl->team16_cus / T) * T;
     const int nteams = grid / T;
     if ((batch + nteams - 1) / nteams > 65535) return 0;
+    if (cp.xstride < 1 || cp.xstride > 0x7fffffffLL || batch > 0x7fffffffLL) return 0;      // (the kernel's 32-bit signal index and stride)
     // slots: a CU runs at most held_pos list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
     // 2 lead + 2 signals later at the earliest (fsst_team16.hpp "Progress")
     const int held_pos = WPB * (DEPTH + 3);                  // list positions a CU's waves hold: DEPTH held + transformed + landed + drawn each
