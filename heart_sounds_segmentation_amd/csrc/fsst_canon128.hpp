@@ -141,43 +141,45 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
     TileEnergy te = tile_energy(e2, s1, 0.0f);           // (E and S1: the reduction of every canonical-band kernel; the count does not ride along)
     te.C = static_cast<float>(max(inside, 0));
     te.dcdom = te.E > 0.0f && te.S1 * te.S1 >= kDcTheta * te.C * te.E;
-    float E = te.E, mean = 0.0f, Edc = 0.0f;
-    float x[3] = {sreg[0], sreg[1], sreg[2]};
+    // scale, records: one body for both arms below (an offset tile stages x - mean; merged into one path the plain tile paid for the
+    // other's copies and selects: ten vector instructions per group of the team kernel)
+    auto stage = [&](const float (&x)[3], float Es, float E, float mean) -> CanonTile {
+        const int eb = static_cast<int>((__float_as_uint(Es) >> 23) & 0xffu);         // biased exponent (0: zero / denormal tile)
+        const int hb = (eb - 127 + 2) >> 1;                                             // sqrt(E) < 2^hb
+        const int se = (eb == 0 || eb == 255) ? 127 : 127 + 14 - hb;                    // biased exponent of the sample scale
+        const float sx = __uint_as_float(static_cast<unsigned>(se) << 23);
+        CanonTile t;
+        t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
+        t.R2s = r2scale_s * (E * sx) * sx;
+        t.eoff = (mean != 0.0f) ? kOffsetErr2 : 0.0f;
+        t.r2s = r2scale_s;
+        t.mean_s = mean * sx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = x[k] * sx;
+            const _Float16 x1 = static_cast<_Float16>(v);
+            const _Float16 x2 = static_cast<_Float16>(v - static_cast<float>(x1));
+            const unsigned b1 = __builtin_bit_cast(unsigned short, x1), b2 = __builtin_bit_cast(unsigned short, x2);
+            xrec[lane + 64 * k] = u2{b1 | (b1 << 16), b2 | (b2 << 16)};      // (lane + 128 < kCanonRecs: no predicate)
+        }
+        wave_sync();
+        return t;
+    };
     if (__builtin_expect(te.E > 0.0f && te.S1 * te.S1 >= kMeanTheta * te.C * te.E, 0)) {
         if constexpr (!OFFS) { CanonTile r{}; r.mean_s = __builtin_nanf(""); return r; }
-        mean = te.S1 / te.C;
-        float ea = 0.0f;
+        const float mean = te.S1 / te.C;
+        float x[3], ea = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int gi = t0 + lane + 64 * k - 64;
             x[k] = (gi >= 0 && gi < n) ? sreg[k] - mean : 0.0f;
             ea = fmaf(x[k], x[k], ea);
         }
-        E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(ea, 0.0f, 0.0f, 0.0f))));     // (recomputed: E - S1^2 / n cancels)
-        Edc = te.S1 * mean;
+        const float E = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(piece_sums(ea, 0.0f, 0.0f, 0.0f))));     // (recomputed: E - S1^2 / n cancels)
+        // (a tile that is nothing but its mean has E = 0: the scale then comes from the mean, whose spectrum is all there is)
+        return stage(x, (E > 0.0f) ? E : te.S1 * mean, E, mean);
     }
-    // (a tile that is nothing but its mean has E = 0: the scale then comes from the mean, whose spectrum is all there is)
-    const float Es = (E > 0.0f) ? E : Edc;
-    const int eb = static_cast<int>((__float_as_uint(Es) >> 23) & 0xffu);         // biased exponent (0: zero / denormal tile)
-    const int hb = (eb - 127 + 2) >> 1;                                             // sqrt(E) < 2^hb
-    const int se = (eb == 0 || eb == 255) ? 127 : 127 + 14 - hb;                    // biased exponent of the sample scale
-    const float sx = __uint_as_float(static_cast<unsigned>(se) << 23);
-    CanonTile t;
-    t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
-    t.R2s = r2scale_s * (E * sx) * sx;
-    t.eoff = (mean != 0.0f) ? kOffsetErr2 : 0.0f;
-    t.r2s = r2scale_s;
-    t.mean_s = mean * sx;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float v = x[k] * sx;
-        const _Float16 x1 = static_cast<_Float16>(v);
-        const _Float16 x2 = static_cast<_Float16>(v - static_cast<float>(x1));
-        const unsigned b1 = __builtin_bit_cast(unsigned short, x1), b2 = __builtin_bit_cast(unsigned short, x2);
-        xrec[lane + 64 * k] = u2{b1 | (b1 << 16), b2 | (b2 << 16)};      // (lane + 128 < kCanonRecs: no predicate)
-    }
-    wave_sync();
-    return t;
+    return stage(sreg, te.E, te.E, 0.0f);
 }
 
 // Rare path of a displaced source (oracle/fsst_oracle.c steps 4-6 in float32), as displaced_source of fsst_mfma128.hpp
@@ -328,6 +330,33 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         }
     }
 
+    // Conjugate partners.  Source s of class r pairs with bin nwin - (r + 8 s): class 8 - r, index 15 - s -- the OTHER array of the lane
+    // -- except in lane group 0, whose two classes are their own partners: class 0 pairs with za[(16 - s) & 15], class 4 with zb[15 - s].
+    // Selecting per stripe cost four v_cndmask each (32 per group); instead lane group 0 alone (exec = lanes 0..15) rotates the upper
+    // halves of its arrays once, zb[m] <- za[m + 1], za[m] <- zb[m] (m = 8..15; the indices 8..15 are partners only, never sources), and
+    // every lane reads PA = zb[15 - s], PB = za[15 - s]: 17 moves of a register pair.
+#ifndef HSS_CANON_SELECT_PARTNERS
+    {
+        f2 t0;
+        asm volatile("s_mov_b64 exec, 0xffff\n\t"
+                     "v_mov_b64 %[t], %[b8]\n\t"
+                     "v_mov_b64 %[b8], %[a9]\n\tv_mov_b64 %[a9], %[b9]\n\t"
+                     "v_mov_b64 %[b9], %[a10]\n\tv_mov_b64 %[a10], %[b10]\n\t"
+                     "v_mov_b64 %[b10], %[a11]\n\tv_mov_b64 %[a11], %[b11]\n\t"
+                     "v_mov_b64 %[b11], %[a12]\n\tv_mov_b64 %[a12], %[b12]\n\t"
+                     "v_mov_b64 %[b12], %[a13]\n\tv_mov_b64 %[a13], %[b13]\n\t"
+                     "v_mov_b64 %[b13], %[a14]\n\tv_mov_b64 %[a14], %[b14]\n\t"
+                     "v_mov_b64 %[b14], %[a15]\n\tv_mov_b64 %[a15], %[b15]\n\t"
+                     "v_mov_b64 %[b15], %[a0]\n\t"
+                     "v_mov_b64 %[a8], %[t]\n\t"
+                     "s_mov_b64 exec, -1"
+                     : [t] "=&v"(t0), [a8] "+v"(za[8]), [a9] "+v"(za[9]), [a10] "+v"(za[10]), [a11] "+v"(za[11]), [a12] "+v"(za[12]),
+                       [a13] "+v"(za[13]), [a14] "+v"(za[14]), [a15] "+v"(za[15]), [b8] "+v"(zb[8]), [b9] "+v"(zb[9]), [b10] "+v"(zb[10]),
+                       [b11] "+v"(zb[11]), [b12] "+v"(zb[12]), [b13] "+v"(zb[13]), [b14] "+v"(zb[14]), [b15] "+v"(zb[15])
+                     : [a0] "v"(za[0]));
+    }
+#endif
+
     // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
     unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
     unsigned ob = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rBi - C::COV0)));
@@ -347,9 +376,13 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         constexpr int s = decltype(SS)::value;
         constexpr bool STA = C::stored(s, 0), STB = C::stored(s, 1);
         constexpr float TA = C::thr(s, 0), TB = C::thr(s, 1);
+#ifndef HSS_CANON_SELECT_PARTNERS
+        const f2 PA = zb[NT - 1 - s], PB = za[NT - 1 - s];
+#else
         const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
         const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
         const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
+#endif
         f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
         f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
         const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
