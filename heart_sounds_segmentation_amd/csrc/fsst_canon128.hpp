@@ -30,6 +30,12 @@ using u4 = unsigned __attribute__((ext_vector_type(4)));
 using lds_u2 = __attribute__((address_space(3))) u2;
 using lds_u4 = __attribute__((address_space(3))) u4;
 
+// A rare path that loads from memory (float64 passes, offset tables, register reloads the compiler puts there) ends with an explicit
+// "all my loads are back": the compiler's wait-count pass merges what is pending over ALL paths into the hot loop's head, and a reload
+// left pending by the rounding-tie path made it wait for every outstanding memory operation -- the next tile's samples and the previous
+// group's stores, both issued a moment ago on purpose -- in the middle of the next group's fold.  (s_waitcnt vmcnt(0), expcnt / lgkmcnt
+// untouched; as a builtin, not inline assembly: the pass must see it.)
+#define HSS_RARE_VMEM_DONE() __builtin_amdgcn_s_waitcnt(0x0f70)
 constexpr int kCanonTileFrames = 64;                     // frames per aligned tile (4 groups = one statistics block)
 constexpr int kCanonRecs = 192;                          // sample records per tile: 64 + 127, rounded up
 constexpr int kCanonOpFloats = 16 * 64 * 4;              // f16 A operand: [16 taps][64 lanes][8 halves] = 16 kB
@@ -436,6 +442,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
                                          C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
+        HSS_RARE_VMEM_DONE();
     } else
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(f_ties) != 0, 0)) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
@@ -443,6 +450,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         resolve_bitmap<NWIN, false, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
         f_dirty = flag[0];
+        HSS_RARE_VMEM_DONE();
     }
     if (__builtin_amdgcn_readfirstlane(f_dirty) != 0) {      // (rare) fold the displaced plane into the own plane, clear it
         f2* src = own_base + j * C::LD + C::KOFF + g;

@@ -452,6 +452,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
         c_valid = false;
+        // The step's ONE wait for memory, said out loud.  Outstanding here: the next tile's samples and the previous group's stores, both a
+        // whole transform old.  Left to the compiler the wait sat in the middle of the fold, a hundred instructions after those samples and
+        // stores were issued: its wait-count pass merges what may be pending over every path through the loop, and a register reload
+        // inside the transform's rare paths made it protect the fold's registers at the head of the loop (HSS_RARE_VMEM_DONE, fsst_canon128.hpp).
+#ifndef HSS_T16_NO_STEPWAIT
+        HSS_RARE_VMEM_DONE();
+#endif
         if (d_valid) land();
         // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
         //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
