@@ -5,8 +5,8 @@ tag=$1; shift
 R=$(pwd); cd /tmp && export TMPDIR=/tmp; cd $R
 for lib in "$@"; do
   O=$R/gpurun_out/$tag.$(basename $lib .so); mkdir -p $O
-  T16_ROUNDS=2 T16_EXECS=4 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/p1 -o p1 -- python tools/t16_probe.py $lib > $O/p1.log 2>&1
-  T16_ROUNDS=2 T16_EXECS=4 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/p2 -o p2 -- python tools/t16_probe.py $lib > $O/p2.log 2>&1
+  T16_OFFSET=${T16_OFFSET:-0} T16_ROUNDS=2 T16_EXECS=4 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/p1 -o p1 -- python tools/t16_probe.py $lib > $O/p1.log 2>&1
+  T16_OFFSET=${T16_OFFSET:-0} T16_ROUNDS=2 T16_EXECS=4 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/p2 -o p2 -- python tools/t16_probe.py $lib > $O/p2.log 2>&1
   python - <<PY
 import sqlite3, glob
 out = {}
