@@ -371,6 +371,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
     f2* row_disp = disp_base + j * C::LDF;
     float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
+    bool visited = false;                                // (wave-uniform) some stripe took the rare path: only then are the flags in LDS worth a look
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 4
     {   f2 accz = {0.0f, 0.0f};
         static_for<NT>([&](auto I) { accz += za[decltype(I)::value] + zb[decltype(I)::value]; });
@@ -398,7 +399,10 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 3      // development (tools/canon_ablate.sh): results invalid
         if ((ma | mb) && tile.R2s == 123.0f) {
 #else
-        if (__builtin_expect(ma | mb, 0)) {                  // (unlikely: the rare path is laid out behind the hot code, no taken branch over it)
+        // (unlikely: the rare path is laid out behind the hot code, no taken branch over it; the test is the wave's, not the lane's, so that
+        //  `visited` is a scalar)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(ma | mb) != 0ull, 0)) {
+            visited = true;
 #endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
@@ -408,8 +412,12 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     });
     CPROBE(2);
     wave_sync();
-    int f_dirty = flag[0], f_ties = flag[1];             // one LDS round trip for both per-group flags (the empty statement keeps
-    asm volatile("" : "+v"(f_dirty), "+v"(f_ties));      // the compiler from sinking the second read behind the first branch)
+    // the per-group flags (the displaced plane is dirty; the tie bitmap has a bit) are set by the rare path only: a group that never went
+    // there skips the trip to LDS and its wait.  One round trip for both (the empty statement keeps
+    // the compiler from sinking the second read behind the first branch).
+    int f_dirty = 0, f_ties = 0;
+    if (visited) { f_dirty = flag[0]; f_ties = flag[1]; }
+    asm volatile("" : "+v"(f_dirty), "+v"(f_ties));
     auto signal_sample = [&](int i) -> double {
         const int gi = tg + i - NWIN / 2;
         const float* xs;

@@ -251,16 +251,23 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     // a ticket the wave holds unpublished while it waits must not belong to the signal it waits for).  The counter only grows and
     // stands behind this wave's last ticket: when the position after that one already lies in a later signal there is nothing to
     // look at (one LDS round trip instead of two).  The block's `dead` word rides along with the ticket.
-    auto draw = [&](int after_ko) {
-        int qi = 0x7fffffff;
-        unsigned dd = 0u;
+    // (in two halves: the LDS operations are ISSUED by draw_ask -- the main loop asks right behind the atomic that counts its partial
+    //  in, one wait for both round trips -- and the ticket is looked at by draw_take)
+    int ask_qi = 0x7fffffff;
+    unsigned ask_dd = 0u;
+    auto draw_ask = [&](int after_ko) {
+        ask_qi = 0x7fffffff;
+        ask_dd = 0u;
         const bool known = after_ko < 0 || ((q_last + 1) >> cpcs) > after_ko;
         if (lane == 0) {
             const bool go = known || (__hip_atomic_load(next_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> cpcs) > after_ko;
-            if (go) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            dd = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (go) ask_qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ask_dd = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        qi = __builtin_amdgcn_readfirstlane(qi);
+    };
+    auto draw_take = [&]() {
+        int qi = __builtin_amdgcn_readfirstlane(ask_qi);
+        const unsigned dd = ask_dd;
         saw_dead = __builtin_amdgcn_readfirstlane(dd) != 0u;
         d_valid = false;
         while (qi < nwork) {
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             canon_fetch(xsig, n, ((g_d + cg0) & ~3) * 16, lane_o, sreg);
         }
     };
+    auto draw = [&](int after_ko) { draw_ask(after_ko); draw_take(); };
 
     auto stats_ready = [&](int ko) -> bool {             // the CU already has this signal's statistics
         unsigned have = 0u;
@@ -484,6 +492,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             const int expect = min(kStatBlock, G - bfirst);
             int before = 0;
             if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef HSS_T16_SERIAL_RELEASE
+            draw_ask(ko_cur);
+#endif
             if (__builtin_amdgcn_readfirstlane(before) + 1 == expect) {
                 __builtin_amdgcn_s_setprio(3);           // (a signal's statistics wait for its last block)
                 if (lane == 0) __hip_atomic_store(pcnt_lds + 2 * ps + (pos >> 2), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -509,8 +520,84 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 __builtin_amdgcn_s_setprio(0);
             }
         }
+#ifndef HSS_T16_SERIAL_RELEASE
+        draw_take();
+#else
         draw(ko_cur);
-        // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in
+#endif
+        // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in.
+        // Two trips to LDS for all of it (as separate steps -- ready word; column classes; three statistics entries, each waited for;
+        // per float4 of the image its offsets, then its cells -- it was eleven, one behind the other, a tenth of the wave's time per group):
+        // first the words that only depend on the lane and the slot -- is the leaving group's signal resolved, which statistics entry and
+        // which cells each of the lane's three float4 takes --, then, behind one wait, the statistics entries and the new image's cells.
+#ifndef HSS_T16_SERIAL_RELEASE
+        {
+            int ko_o = 0, g_o = 0;
+            static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) { ko_o = ko_hs[decltype(S)::value]; g_o = g_hs[decltype(S)::value]; } });
+            const bool full = nheld == DEPTH;
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+            const unsigned cofs = cls_lds[lane_r];
+            const unsigned pk0 = ppk_lds[lane_r], pk1 = ppk_lds[64 + lane_r], pk2 = ppk_lds[128 + lane_r];
+            const unsigned have = __hip_atomic_load(ready + (ko_o & smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (every lane: a broadcast read)
+            if (full) {
+#if !(defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2))
+                if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(have))) != static_cast<unsigned>(ko_o) + 1u) signal_statistics(ko_o);
+#endif
+            } else ++nheld;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
+            asm volatile("" : "+s"(obase));
+            auto cell = [&](unsigned off) -> f2 {
+                const lds_float* q = (const lds_float*)static_cast<size_t>(obase + off);
+                return f2{q[0], q[2]};
+            };
+            const f2 lo0 = cell(pk0 & 0xffffu), hi0 = cell(pk0 >> 16), lo1 = cell(pk1 & 0xffffu), hi1 = cell(pk1 >> 16),
+                     lo2 = cell(pk2 & 0xffffu), hi2 = cell(pk2 >> 16);
+            const f2 sc = {inv_cur, inv_cur};
+            static_for<DEPTH>([&](auto S) {
+                constexpr int sl = decltype(S)::value;
+                if (slot == sl) {
+                    if (full) {
+                        const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_o & smask));
+                        const float4 t0 = *reinterpret_cast<const float4*>(tb + (cofs & 0xffu));
+                        const float4 t1 = *reinterpret_cast<const float4*>(tb + ((cofs >> 8) & 0xffu));
+                        const float4 t2 = *reinterpret_cast<const float4*>(tb + ((cofs >> 16) & 0xffu));
+                        char* ob = reinterpret_cast<char*>(P()->out) + static_cast<unsigned long long>(static_cast<unsigned>(team + ko_o * nteams)) * sig_bytes +
+                                   static_cast<unsigned>(g_o * (16 * 2 * K * 4));                                              // (wave-uniform)
+                        const unsigned voff = static_cast<unsigned>(lane_r) * 16u;
+                        const int nvalid = min(16, ncols - g_o * 16);
+                        auto put = [&](auto I, float4 tt) {
+                            constexpr int i = decltype(I)::value;
+                            const f2 l = held_zscore<6 * sl + 2 * i>(f2{tt.x, tt.y});
+                            const f2 h = held_zscore<6 * sl + 2 * i + 1>(f2{tt.z, tt.w});
+#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 2      // development: the arithmetic without the stores
+                            { f2 l2 = l, h2 = h; asm volatile("" :: "v"(l2), "v"(h2)); }
+#else
+                            __builtin_nontemporal_store(f4{l.x, l.y, h.x, h.y}, reinterpret_cast<f4*>(ob + (voff + 1024u * static_cast<unsigned>(i))));
+#endif
+                        };
+                        const float4 tts[3] = {t0, t1, t2};
+                        if (__builtin_expect(nvalid == 16, 1)) {
+                            static_for<3>([&](auto I) {
+                                constexpr int i = decltype(I)::value;
+                                if constexpr (64 * (i + 1) <= 8 * K) put(I, tts[i]);
+                                else if constexpr (64 * i < 8 * K) { if (lane_r + 64 * i < 8 * K) put(I, tts[i]); }
+                            });
+                        } else {
+                            asm volatile("");
+                            const int lim = nvalid * (K >> 1);
+                            static_for<3>([&](auto I) { if (lane_r + 64 * decltype(I)::value < lim) put(I, tts[decltype(I)::value]); });
+                        }
+                    }
+                    held_put<6 * sl + 0>(lo0, sc); held_put<6 * sl + 1>(hi0, sc);
+                    held_put<6 * sl + 2>(lo1, sc); held_put<6 * sl + 3>(hi1, sc);
+                    held_put<6 * sl + 4>(lo2, sc); held_put<6 * sl + 5>(hi2, sc);
+                    ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
+                }
+            });
+        }
+#else
         int ko_o = 0;
         static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
         const bool full = nheld == DEPTH;
@@ -528,6 +615,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
             }
         });
+#endif
         slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
         wave_sync();
     }
