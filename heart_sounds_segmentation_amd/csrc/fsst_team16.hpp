@@ -478,23 +478,46 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             const int pos = g_cur & (cpc - 1);           // position among the CU's groups of this signal
             const int ps = ko_cur & (PSLOTS - 1);
             float* pe = part_lds + (ps * kT16MaxCpc + pos) * kT16PartFloats;
-            {   // the first lane of each row writes its row's sum, lane 0 the pivot pair: two stores under literal exec masks (the
-                // predicates as compares and selects were 20 instructions; LDS operations of a wave execute in order, the ones
-                // issued here only make the compiler's own counts conservative)
-                const unsigned pa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)pe)) + (static_cast<unsigned>(lane_o) >> 4) * 4u;
+            // the first lane of each row writes its row's sum, lane 0 the pivot pair: two stores under literal exec masks (the
+            // predicates as compares and selects were 20 instructions).  Behind them, still lane 0 alone and in ONE statement: the atomic
+            // that counts the partial in, the atomic that draws the next ticket (draw_ask's, when the counter need not be looked at
+            // first) and the block's `dead` word -- one wait for the three round trips.  (As builtins the compiler's atomic optimiser
+            // made each a wave reduction that is read back on the spot, one round trip after the other.)  LDS operations of a wave
+            // execute in order: the partial is there before it is counted.
+            const unsigned pa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)pe)) + (static_cast<unsigned>(lane_o) >> 4) * 4u;
+            const unsigned pcnt_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)(pcnt_lds + 2 * ps + (pos >> 2))));
+            int before = 0;
+#ifndef HSS_T16_SERIAL_RELEASE
+            const bool known = ((q_last + 1) >> cpcs) > ko_cur;
+            if (__builtin_expect(known, 1)) {
+                const unsigned nq_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)next_q));
+                unsigned one = 1u, before_v, qi_v, dd_v;
+                unsigned long long keep;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\tds_write_b32 %4, %5\n\t"
+                             "s_mov_b64 exec, 1\n\tds_write_b64 %4, %6 offset:16\n\t"
+                             "ds_add_rtn_u32 %1, %7, %9\n\tds_add_rtn_u32 %2, %8, %9\n\tds_read_b32 %3, %8 offset:4\n\t"
+                             "s_mov_b64 exec, %0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(keep), "=&v"(before_v), "=&v"(qi_v), "=&v"(dd_v)
+                             : "v"(pa), "v"(w), "v"(piv), "v"(pcnt_a), "v"(nq_a), "v"(one) : "memory");
+                before = static_cast<int>(before_v);
+                ask_qi = static_cast<int>(qi_v);         // (lane 0's are the values: draw_take reads the first lane)
+                ask_dd = dd_v;
+                wave_sync();
+            } else
+#endif
+            {
                 unsigned long long keep;
                 asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\tds_write_b32 %1, %2\n\t"
                              "s_mov_b64 exec, 1\n\tds_write_b64 %1, %3 offset:16\n\ts_mov_b64 exec, %0"
                              : "=&s"(keep) : "v"(pa), "v"(w), "v"(piv) : "memory");
+                wave_sync();
+                if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef HSS_T16_SERIAL_RELEASE
+                draw_ask(ko_cur);
+#endif
             }
-            wave_sync();
             const int blk = g_cur >> 2, bfirst = blk << 2;                       // kStatBlock = 4
             const int expect = min(kStatBlock, G - bfirst);
-            int before = 0;
-            if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef HSS_T16_SERIAL_RELEASE
-            draw_ask(ko_cur);
-#endif
             if (__builtin_amdgcn_readfirstlane(before) + 1 == expect) {
                 __builtin_amdgcn_s_setprio(3);           // (a signal's statistics wait for its last block)
                 if (lane == 0) __hip_atomic_store(pcnt_lds + 2 * ps + (pos >> 2), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
