@@ -97,13 +97,20 @@ struct CanonCfg {
 // in the fp32 table of fsst_core128_kernel.  `cs` = 2^sc scales the constants into [2^13, 2^14).
 // (built in hssfsst.hip: canon_build_atab)
 
+#ifndef HSS_OFFERR
+#define HSS_OFFERR 0.0625f
+#endif
+constexpr float kOffsetErr2 = HSS_OFFERR;                   // (5e-7 / 2e-6)^2: V = V' + mean x Yc is good to 4e-7 R' + 1.2e-7 |mean Yc|, and |mean Yc| <= |V| + R':
+                                                         // the tie bound of such a tile is tau^2 = 4e-12 (1 + |shift|)^2 (R'^2 + kOffsetErr2 |V|^2) / |V|^2
 // One tile's scale, as the kernels hand it around (wave-uniform).
 struct CanonTile {
     float R2s;            // error-bound scale of the tile in SCALED units (see "Rounding ties" in fsst_mfma128.hpp)
-    float eoff;           // != 0 with mean_s: the added offset term's own rounding, relative to |V|^2, in units of the tie bound
     float inv;            // 1 / (sample scale x constant scale): features = plane values x inv (a power of two)
     float r2s;            // the plan's r2scale in scaled units: R^2 = r2s x (sum of squares of scaled samples)
     float mean_s;         // != 0: the tile's mean was taken out of the records; this is it, in scaled sample units ("Offsets")
+    // != 0 with mean_s: the added offset term's own rounding, relative to |V|^2, in units of the tie bound (made where the rare path wants
+    // it: as a field it was one more value held across the transform, and the first one the register allocator sent to scratch)
+    __device__ __forceinline__ float eoff() const { return mean_s != 0.0f ? kOffsetErr2 : 0.0f; }
 };
 
 // Offsets.  float32 resolves a feature to ~4e-7 of its frame's spectrum norm.  A recording that rides on an offset (an ADC bias,
@@ -124,11 +131,6 @@ constexpr int kCanonYcRight = 80;                         // right-edge frames t
 // the 16 lanes of a lane group (consecutive frames) read consecutive words of the edge tables
 constexpr int kCanonZcFloats = kCanonYcFrame + 4 * 32 * 64 * 2 + 4 * 32 * kCanonYcRight * 2;
 constexpr float kMeanTheta = 0.5f;                       // the mean is taken out when S1^2 >= kMeanTheta n E
-#ifndef HSS_OFFERR
-#define HSS_OFFERR 0.0625f
-#endif
-constexpr float kOffsetErr2 = HSS_OFFERR;                   // (5e-7 / 2e-6)^2: V = V' + mean x Yc is good to 4e-7 R' + 1.2e-7 |mean Yc|, and |mean Yc| <= |V| + R':
-                                                         // the tie bound of such a tile is tau^2 = 4e-12 (1 + |shift|)^2 (R'^2 + kOffsetErr2 |V|^2) / |V|^2
 
 // Stores the tile's 191 samples (three per lane, sreg[k] = sample lane + 64 k of the aligned tile that starts at output column
 // t0, zero outside the signal) as records {x1 | x1 << 16, x2 | x2 << 16} and returns the scales.  The scale exponent comes
@@ -157,7 +159,6 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
         CanonTile t;
         t.inv = __uint_as_float(static_cast<unsigned>(254 - se) << 23) * inv_c;
         t.R2s = r2scale_s * (E * sx) * sx;
-        t.eoff = (mean != 0.0f) ? kOffsetErr2 : 0.0f;
         t.r2s = r2scale_s;
         t.mean_s = mean * sx;
 #pragma unroll
@@ -251,7 +252,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     // (TAPB taps at a time: all 16 are independent, and left alone the scheduler loads every operand first -- 128 registers.
     //  A double-buffered variant with every LDS operation issued from inline assembly -- batch k + 1 requested before batch k
     //  is waited for -- was built and measured: 0.2187 vs 0.2157 ms at 16 waves per CU, no difference at 8: LDS latency is
-    //  not what this phase waits for.)
+    //  not what this phase waits for.  Round 5 built it again for the team kernel, s_waitcnt lgkmcnt(4) between the batches:
+    //  0.1733 vs 0.1713 / 0.1768 ms in one run, 2898 vs 2918 wave quad-cycles per group -- inside the noise, not kept.)
     static_for<NT / TAPB>([&](auto GG) {
         constexpr int g0 = decltype(GG)::value * TAPB;
         u4 a[TAPB], b[TAPB];
@@ -406,8 +408,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
-            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, tile.eoff, cellA, STA);
-            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, tile.eoff, cellB, STB);
+            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, tile.eoff(), cellA, STA);
+            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, tile.eoff(), cellB, STB);
         }
     });
     CPROBE(2);
