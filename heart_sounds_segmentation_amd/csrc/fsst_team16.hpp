@@ -13,9 +13,9 @@
 //     a signal passes through the team in about one group time;
 //   * a wave holds up to DEPTH = 2 group images -- three float4 per lane and group, 24 registers -- across further groups'
 //     transforms (canon_group of fsst_canon128.hpp, the arithmetic of every other canonical-band kernel: bit-identical
-//     features on every z-score path): 24 + the transform's ~103 = 127 of the 128 registers of four waves per SIMD (the one
-//     spill, 20 bytes, sits in front of the float64 whole-group loop of the rounding-tie path -- code object checked);
-//     the LDS regions are those of fsst_canon_kernel;
+//     features on every z-score path): 24 FIXED registers (v104 .. v127, see below) + 104 for the transform = the 128 of four
+//     waves per SIMD (no scratch in the hot loop -- the spills sit in the float64 and offset-edge paths; listing checked);
+//     a strict first-in first-out: a held group leaves when its slot is needed; the LDS regions are those of fsst_canon_kernel;
 //   * a CU takes CONSECUTIVE groups of a signal (two blocks of kStatBlock = 4), keeps their statistics partials (the six float32
 //     numbers of the two-launch path) in LDS, and the wave that delivers a block's last partial forms the block's float64 sums
 //     and publishes them as eight tagged 8-byte words in the team's mailbox (relaxed agent-scope atomics: no fence, no cache
@@ -24,11 +24,16 @@
 //     statistics claims it (LDS), fetches the signal's <= 32 block sums from the mailbox -- two per lane, straight into the lane
 //     that adds them -- and finishes as stats_from_blocks() does (fsst_kernels.hpp: the same instructions on the same numbers as
 //     the two-launch path), leaving {mean, 1/std} x 2 in LDS for its 15 siblings.
-// What limits it (profiles/r04_team_occupancy.txt): a resolve is two trips through the memory system (the last partial
-// becoming visible, the copy) plus the sums, ~5 us against a group time of 4.5 us; with two held groups about 45 % of the
-// releases still wait.  Measured and rejected: a third held group (12 more registers: one image spills to scratch in the hot
-// loop), three waves per SIMD with four held groups (the transform loses 25 %), parking images in the free LDS, resolving
-// early (blocking or through global_load_lds copies looked at a group later), releasing in the middle of the transform.
+// What limits it (profiles/r04_team_occupancy.txt, profiles/r05_team_diet.txt): instruction issue -- 527 vector + 16 matrix
+// instructions per group on a SIMD that four waves share, a third of a wave's cycles spent waiting for an issue slot -- and, for
+// ~7 us of the kernel, the statistics: a resolve is two trips through the memory system (the last partial becoming visible,
+// the copy; ~2.3 us each under the kernel's own write stream, inside one XCD as across: tools/mail_latency3.hip) plus the sums
+// against a group time of ~5 us.  Measured and rejected: a third held group (12 more registers: one image spills to scratch in
+// the hot loop; parked in global memory: the waits vanish, the traffic costs 6 %), three waves per SIMD with four held groups
+// (the transform loses 25 %), parking images in the free LDS, resolving early (blocking or through global_load_lds copies
+// looked at a group later), releasing in the middle of the transform, teams inside one XCD, one accumulating plane (LDS float
+// atomics: 0.6 lanes per clock and CU).  Offsets: a tile that rides on an offset is transformed HERE (canon_land / canon_group,
+// "Offsets"), no launch is given up for it.
 //
 // Progress.  A wave publishes a group before it waits for anything, and it waits only for the signal of the oldest group it
 // HOLDS.  Besides the held groups it has up to two tickets it has not published yet (one landed, one drawn with its samples
@@ -406,9 +411,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     };
 
     // ---- the held groups: images in registers (feature units, un-normalised), waiting for their signals' statistics.  A strict
-    // first-in first-out of DEPTH slots, the main loop unrolled DEPTH times: step s fills slot s, after the group that sat there
-    // -- the oldest the wave holds -- has left.  (A ring with early releases, whose slots were picked at run time, cost a dozen
-    // register moves per group at the loop head and a page of scalar bookkeeping; nothing is gained by a group leaving early.)
+    // first-in first-out of DEPTH slots: the steps take the slots in turn (`slot`, a scalar; the two slots' code stands side by
+    // side behind one scalar branch), a step fills its slot after the group that sat there -- the oldest the wave holds -- has
+    // left.  (A ring with early releases cost a dozen register moves per group at the loop head and a page of scalar bookkeeping,
+    // nothing is gained by a group leaving early; the loop unrolled DEPTH times with static slots put an image into scratch.)
     int nheld = 0;
     int ko_hs[DEPTH], g_hs[DEPTH];
 #pragma unroll
