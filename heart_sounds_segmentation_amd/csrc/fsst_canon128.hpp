@@ -343,7 +343,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     // Selecting per stripe cost four v_cndmask each (32 per group); instead lane group 0 alone (exec = lanes 0..15) rotates the upper
     // halves of its arrays once, zb[m] <- za[m + 1], za[m] <- zb[m] (m = 8..15; the indices 8..15 are partners only, never sources), and
     // every lane reads PA = zb[15 - s], PB = za[15 - s]: 17 moves of a register pair.
-#ifndef HSS_CANON_SELECT_PARTNERS
     {
         f2 t0;
         asm volatile("s_mov_b64 exec, 0xffff\n\t"
@@ -363,7 +362,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
                        [b11] "+v"(zb[11]), [b12] "+v"(zb[12]), [b13] "+v"(zb[13]), [b14] "+v"(zb[14]), [b15] "+v"(zb[15])
                      : [a0] "v"(za[0]));
     }
-#endif
 
     // own-plane columns of this lane's two classes as ONE opaque byte address each: stripe s is then the immediate + 64 s
     unsigned oa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<float*>(own_base + j * C::LD + rAi - C::COV0)));
@@ -385,13 +383,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         constexpr int s = decltype(SS)::value;
         constexpr bool STA = C::stored(s, 0), STB = C::stored(s, 1);
         constexpr float TA = C::thr(s, 0), TB = C::thr(s, 1);
-#ifndef HSS_CANON_SELECT_PARTNERS
         const f2 PA = zb[NT - 1 - s], PB = za[NT - 1 - s];
-#else
-        const f2 pa0 = za[(NT - s) & (NT - 1)], pb = zb[NT - 1 - s], pa = za[NT - 1 - s];
-        const f2 PA = f2{isg0 ? pa0.x : pb.x, isg0 ? pa0.y : pb.y};
-        const f2 PB = f2{isg0 ? pb.x : pa.x, isg0 ? pb.y : pa.y};
-#endif
         f2 a1 = mix_re(za[s], PA), a2 = mix_im(za[s], PA);
         f2 b1 = mix_re(zb[s], PB), b2 = mix_im(zb[s], PB);
         const f2 dna = dn_second(a2, dn_first(a1, tiny)), dnb = dn_second(b2, dn_first(b1, tiny));
@@ -536,21 +528,7 @@ __device__ __forceinline__ void canon_image_to(const f2* own_base, const unsigne
         sink(i, f4{lo.x, lo.y, hi.x, hi.y});
     });
 }
-// The same gather, the pairs handed over UNSCALED with their float4's index as a compile-time constant (fsst_team16_kernel scales them
-// into fixed registers)
-template <int KLO, int KC, class Sink>
-__device__ __forceinline__ void canon_image_raw(const f2* own_base, const unsigned* ppk, int lane_o, Sink sink)
-{
-    unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
-    asm volatile("" : "+s"(obase));
-    static_for<3>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const unsigned pk = ppk[i * 64 + lane_o];
-        const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
-        const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
-        sink(I, f2{q0[0], q0[2]}, f2{q1[0], q1[2]});
-    });
-}
+// (fsst_team16_kernel gathers the image itself, in one batch with the words of the group that leaves: fsst_team16.hpp)
 template <int KLO, int KC>
 __device__ __forceinline__ void canon_image(const f2* own_base, const unsigned* ppk, float inv, int lane_o, f4 (&o)[3])
 {

@@ -470,9 +470,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         // whole transform old.  Left to the compiler the wait sat in the middle of the fold, a hundred instructions after those samples and
         // stores were issued: its wait-count pass merges what may be pending over every path through the loop, and a register reload
         // inside the transform's rare paths made it protect the fold's registers at the head of the loop (HSS_RARE_VMEM_DONE, fsst_canon128.hpp).
-#ifndef HSS_T16_NO_STEPWAIT
         HSS_RARE_VMEM_DONE();
-#endif
         if (d_valid) land();
         // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
         //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
@@ -493,7 +491,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             const unsigned pa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)pe)) + (static_cast<unsigned>(lane_o) >> 4) * 4u;
             const unsigned pcnt_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)(pcnt_lds + 2 * ps + (pos >> 2))));
             int before = 0;
-#ifndef HSS_T16_SERIAL_RELEASE
             const bool known = ((q_last + 1) >> cpcs) > ko_cur;
             if (__builtin_expect(known, 1)) {
                 const unsigned nq_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)next_q));
@@ -509,18 +506,14 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 ask_qi = static_cast<int>(qi_v);         // (lane 0's are the values: draw_take reads the first lane)
                 ask_dd = dd_v;
                 wave_sync();
-            } else
-#endif
-            {
+            } else {
                 unsigned long long keep;
                 asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\tds_write_b32 %1, %2\n\t"
                              "s_mov_b64 exec, 1\n\tds_write_b64 %1, %3 offset:16\n\ts_mov_b64 exec, %0"
                              : "=&s"(keep) : "v"(pa), "v"(w), "v"(piv) : "memory");
                 wave_sync();
                 if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef HSS_T16_SERIAL_RELEASE
                 draw_ask(ko_cur);
-#endif
             }
             const int blk = g_cur >> 2, bfirst = blk << 2;                       // kStatBlock = 4
             const int expect = min(kStatBlock, G - bfirst);
@@ -549,17 +542,12 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 __builtin_amdgcn_s_setprio(0);
             }
         }
-#ifndef HSS_T16_SERIAL_RELEASE
         draw_take();
-#else
-        draw(ko_cur);
-#endif
         // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in.
         // Two trips to LDS for all of it (as separate steps -- ready word; column classes; three statistics entries, each waited for;
         // per float4 of the image its offsets, then its cells -- it was eleven, one behind the other, a tenth of the wave's time per group):
         // first the words that only depend on the lane and the slot -- is the leaving group's signal resolved, which statistics entry and
         // which cells each of the lane's three float4 takes --, then, behind one wait, the statistics entries and the new image's cells.
-#ifndef HSS_T16_SERIAL_RELEASE
         {
             int ko_o = 0, g_o = 0;
             static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) { ko_o = ko_hs[decltype(S)::value]; g_o = g_hs[decltype(S)::value]; } });
@@ -626,25 +614,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 }
             });
         }
-#else
-        int ko_o = 0;
-        static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) ko_o = ko_hs[decltype(S)::value]; });
-        const bool full = nheld == DEPTH;
-        if (full) signal_statistics(ko_o);
-        else ++nheld;
-        static_for<DEPTH>([&](auto S) {
-            constexpr int sl = decltype(S)::value;
-            if (slot == sl) {
-                if (full) emit_held(S, ko_hs[sl], g_hs[sl]);
-                canon_image_raw<KLO, KC>(own_base, ppk_lds, lane_o, [&](auto I, f2 lo, f2 hi) {
-                    constexpr int i = decltype(I)::value;
-                    held_put<6 * sl + 2 * i>(lo, f2{inv_cur, inv_cur});
-                    held_put<6 * sl + 2 * i + 1>(hi, f2{inv_cur, inv_cur});
-                });
-                ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
-            }
-        });
-#endif
         slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
         wave_sync();
     }
