@@ -523,15 +523,25 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 wave_sync();
                 int lane_b = lane;
                 asm volatile("" : "+v"(lane_b));
-                const int q = lane_b & 3, h = q >> 1;
-                const float* pb = part_lds + (ps * kT16MaxCpc + (pos & ~3)) * kT16PartFloats;
+                // lane (pc, q) of a row forms quantity q of the block's piece pc -- the four pieces side by side, not one after the other --
+                // and lanes 0..3 add them IN ORDER, ((0 + m0) + m1) + m2) + m3, the sum of signal_stats()' loop to the last bit
+                const int q = lane_b & 3, h = q >> 1, pc = (lane_b >> 2) & 3;
+                const float* pb = part_lds + (ps * kT16MaxCpc + (pos & ~3) + pc) * kT16PartFloats;
+                const double cnt = static_cast<double>(min(16, ncols - 16 * (bfirst + pc))) * static_cast<double>(K);
+                const double mom = piece_moment(q, static_cast<double>(pb[2 * h]), static_cast<double>(pb[2 * h + 1]), static_cast<double>(pb[4 + h]), cnt);
+                auto from_row = [&](int ctrl) -> double {  // lane i <- lane i + 4 / 8 / 12 of its row (row_shl)
+                    const long long b = __double_as_longlong(mom);
+                    unsigned lo, hi;
+                    if (ctrl == 4) { lo = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b), 0x104, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b >> 32), 0x104, 0xf, 0xf, true); }
+                    else if (ctrl == 8) { lo = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b), 0x108, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b >> 32), 0x108, 0xf, 0xf, true); }
+                    else { lo = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b), 0x10c, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0u, static_cast<unsigned>(b >> 32), 0x10c, 0xf, 0xf, true); }
+                    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+                };
                 double sbk = 0.0;
-                for (int pc = 0; pc < expect; ++pc) {
-                    const int gq = bfirst + pc;
-                    const double cnt = static_cast<double>(min(16, ncols - 16 * gq)) * static_cast<double>(K);
-                    sbk += piece_moment(q, static_cast<double>(pb[pc * kT16PartFloats + 2 * h]), static_cast<double>(pb[pc * kT16PartFloats + 2 * h + 1]),
-                                        static_cast<double>(pb[pc * kT16PartFloats + 4 + h]), cnt);
-                }
+                sbk += mom;                               // (lanes 0..3: pc = 0; `expect` >= 1)
+                if (expect > 1) sbk += from_row(4);
+                if (expect > 2) sbk += from_row(8);
+                if (expect > 3) sbk += from_row(12);
                 const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko_cur) & 0xffffu);
                 const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(sbk));
                 gu64* e = mail + static_cast<size_t>(ko_cur & smask) * nwords + (blk * 4 + q) * 2;
