@@ -210,7 +210,7 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
     }
 #endif
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    move_source<NWIN, true>(row_disp, flag, KLO, KC, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
+    move_source<NWIN, true, false, true>(row_disp, flag, KLO, KC, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
 }
 
 // The group's transform up to and including the scatter: on return the own plane [16][LD] holds the group's synchrosqueezed
@@ -443,7 +443,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         resolve_bitmap<NWIN, true, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD,
                                          C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
-        f_dirty = flag[0];
+        f_dirty = flag[0] != 0 ? -1 : 0;                 // (the float64 pass does not say which columns it added to)
         HSS_RARE_VMEM_DONE();
     } else
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(f_ties) != 0, 0)) {       // (rare) cells whose rounding float32 cannot decide
@@ -451,15 +451,18 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         // 1e-5 bins from a half-integer needs all 24
         resolve_bitmap<NWIN, false, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
-        f_dirty = flag[0];
+        f_dirty = flag[0] != 0 ? -1 : 0;
         HSS_RARE_VMEM_DONE();
     }
     if (__builtin_amdgcn_readfirstlane(f_dirty) != 0) {      // (rare) fold the displaced plane into the own plane, clear it
+        // (flag[0] says which columns were added to -- canon_displaced / move_source<COLS> --: lane group g folds columns g + 4 u, a quad of
+        //  columns that nothing was added to is not looked at: most dirty groups have one or two, and the fold was 30 LDS operations)
+        const unsigned cols = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(f_dirty));
         f2* src = own_base + j * C::LD + C::KOFF + g;
         f2* dsp = disp_base + j * C::LDF + g;
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-            if (4 * u < KC && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
+            if (4 * u < KC && ((cols >> (4 * u)) & 0xfu) != 0u && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
         if (lane_o == 0) *flag = 0;
         wave_sync();
     }

@@ -315,7 +315,8 @@ struct PairList {
     int* cnt;             // (in LDS) additions listed; > kPairListCap: entries were dropped, the group is redone without the list
     int rowoff;           // this lane's frame row of the displaced plane, in cells
 };
-template <int NWIN, bool LANE_OWNS = false, bool LIST = false>
+// COLS (K <= 32): *flag collects WHICH columns of the displaced plane were added to (bit = column), so that the fold looks at those only.
+template <int NWIN, bool LANE_OWNS = false, bool LIST = false, bool COLS = false>
 __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V,
                                             f2* own_cell = nullptr, bool stored = false, PairList* pl = nullptr)
 {
@@ -353,7 +354,10 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
     }
     if (in_row) add(idx, V.x, V.y);
     if (in_twin) add(idm, V.x, -V.y);
-    if (touched) *flag = 1;                             // this wave's displaced plane is no longer zero: ONE write
+    if constexpr (COLS) {
+        const unsigned bits = (in_row ? 1u << idx : 0u) | (in_twin ? 1u << idm : 0u);
+        if (bits != 0u) __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (touched) *flag = 1;                      // this wave's displaced plane is no longer zero: ONE write
 }
 
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
