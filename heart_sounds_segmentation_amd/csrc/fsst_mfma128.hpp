@@ -337,6 +337,24 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
         }
     };
     if (row == kpi) return;                             // rounds back into its own row after all
+    if constexpr (COLS && LANE_OWNS && !LIST) if (klo >= 1 && klo + K <= NWIN / 2) {
+        // a band inside rows 1 .. nwin/2 - 1 (the canonical-band kernels; row 0 is its own twin and keeps the general form below): a
+        // destination is in the band, or -- only above nwin/2 -- its twin is; the twin's arithmetic is spent on the few sources that
+        // wrap around row 0
+        if (stored) *own_cell = f2{0.0f, 0.0f};
+        const int idx = row - klo;
+        if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) {
+            add(idx, V.x, V.y);
+            __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), 1u << idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (row > NWIN / 2 && kpi != 0) {
+            const int idm = (NWIN - row) - klo;
+            if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) {
+                add(idm, V.x, -V.y);
+                __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), 1u << idm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
     const int own = kpi - klo, idx = row - klo;
     const int idm = ((NWIN - row) & (NWIN - 1)) - klo;  // negative-frequency twin: row -> nwin - row, value conj
     const bool in_row = static_cast<unsigned>(idx) < static_cast<unsigned>(K);
