@@ -43,6 +43,8 @@ constexpr int kCanonAtabFloats = kCanonOpFloats + 4 * 128;   // + {cos, sin}(2 p
 constexpr int kCanonLdsTabFloats = kCanonAtabFloats + 4 * 33 * 2;   // what the kernels keep in LDS: + the interior frame of the offset table ("Offsets"), 1 kB
 constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
 // (rounding ties: the bitmap of fsst_mfma128.hpp, "Rounding ties"; the float64 path reads the signal's own samples)
+constexpr int kCanonFlagWords = 8;                       // [0] the displaced plane is dirty [1] the tie bitmap has a bit [2..7] one BYTE per column of the
+                                                         // displaced plane that was added to (canon_displaced -> move_source<COLS>; the fold looks at those)
 constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
 
 template <int KLO, int KC>
@@ -89,7 +91,7 @@ struct CanonCfg {
         return (nd <= 1 ? 0.5f : static_cast<float>(nd) - 0.5f) - static_cast<float>(1 + (nd <= 1 ? 0 : nd)) * kTieMargin;
 #endif
     }
-    static constexpr int wave_floats() { return 2 * kCanonRecs + 2 * 16 * (LD + LDF) + 4 + kCanonTieWords; }
+    static constexpr int wave_floats() { return 2 * kCanonRecs + 2 * 16 * (LD + LDF) + kCanonFlagWords + kCanonTieWords; }
 };
 
 // Host side of the f16 operand table: entry (tap n, lane l, half h): lane l = (kk, row i); h -> fold term q = kk + 4 (h >> 2),
@@ -455,15 +457,18 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         HSS_RARE_VMEM_DONE();
     }
     if (__builtin_amdgcn_readfirstlane(f_dirty) != 0) {      // (rare) fold the displaced plane into the own plane, clear it
-        // (flag[0] says which columns were added to -- canon_displaced / move_source<COLS> --: lane group g folds columns g + 4 u, a quad of
-        //  columns that nothing was added to is not looked at: most dirty groups have one or two, and the fold was 30 LDS operations)
-        const unsigned cols = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(f_dirty));
+        // (flag[2..7] hold one byte per column that was added to -- canon_displaced / move_source<COLS>: a plain byte store per moving lane;
+        //  an atomic OR into one word serialised the lanes and cost a tile in which every cell moves a fifth of its time --: lane group g
+        //  folds columns g + 4 u, and a quad of columns that nothing was added to -- word u is zero -- is not looked at: most dirty groups
+        //  have one or two, and the whole fold is 30 LDS operations.  A float64 pass does not say where it added: all of them.)
+        const bool all = __builtin_amdgcn_readfirstlane(f_dirty) == -1;
+        int cw = (lane_o < 6) ? flag[2 + lane_o] : 0;
         f2* src = own_base + j * C::LD + C::KOFF + g;
         f2* dsp = disp_base + j * C::LDF + g;
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-            if (4 * u < KC && ((cols >> (4 * u)) & 0xfu) != 0u && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
-        if (lane_o == 0) *flag = 0;
+            if (4 * u < KC && (all || __builtin_amdgcn_readlane(cw, u) != 0) && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
+        if (lane_o < kCanonFlagWords && lane_o != 1) flag[lane_o] = 0;
         wave_sync();
     }
     CPROBE(3);
@@ -618,12 +623,12 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
     f2* disp_base = own_base + 16 * C::LD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * C::LDF);
-    int* tq = flag + 4;
+    int* tq = flag + kCanonFlagWords;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
     const int ncols = p.ncols, cend = p.col0 + p.ncols;
     for (int i = lane; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane < 4) flag[lane] = 0;
+    if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
     if (wv == 0) {

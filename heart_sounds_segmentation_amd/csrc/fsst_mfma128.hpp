@@ -315,7 +315,8 @@ struct PairList {
     int* cnt;             // (in LDS) additions listed; > kPairListCap: entries were dropped, the group is redone without the list
     int rowoff;           // this lane's frame row of the displaced plane, in cells
 };
-// COLS (K <= 32): *flag collects WHICH columns of the displaced plane were added to (bit = column), so that the fold looks at those only.
+// COLS (K <= 24): flag[2..7] collect WHICH columns of the displaced plane were added to (a byte per column), so that the fold looks at
+// those only; flag[0] says that there is something to fold, as without COLS.
 template <int NWIN, bool LANE_OWNS = false, bool LIST = false, bool COLS = false>
 __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, int K, int kpi, int row, f2 V,
                                             f2* own_cell = nullptr, bool stored = false, PairList* pl = nullptr)
@@ -343,14 +344,15 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
         // wrap around row 0
         if (stored) *own_cell = f2{0.0f, 0.0f};
         const int idx = row - klo;
+        unsigned char* colb = reinterpret_cast<unsigned char*>(flag + 2);     // one byte per column (K <= 24): plain stores, no atomic
         if (static_cast<unsigned>(idx) < static_cast<unsigned>(K)) {
             add(idx, V.x, V.y);
-            __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), 1u << idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            colb[idx] = 1; *flag = 1;
         } else if (row > NWIN / 2 && kpi != 0) {
             const int idm = (NWIN - row) - klo;
             if (static_cast<unsigned>(idm) < static_cast<unsigned>(K)) {
                 add(idm, V.x, -V.y);
-                __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), 1u << idm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                colb[idm] = 1; *flag = 1;
             }
         }
         return;
@@ -372,10 +374,12 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
     }
     if (in_row) add(idx, V.x, V.y);
     if (in_twin) add(idm, V.x, -V.y);
-    if constexpr (COLS) {
-        const unsigned bits = (in_row ? 1u << idx : 0u) | (in_twin ? 1u << idm : 0u);
-        if (bits != 0u) __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(flag), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else if (touched) *flag = 1;                      // this wave's displaced plane is no longer zero: ONE write
+    if constexpr (COLS) {                               // (bands that take the general form: row 0 inside the band)
+        unsigned char* colb = reinterpret_cast<unsigned char*>(flag + 2);
+        if (in_row) colb[idx] = 1;
+        if (in_twin) colb[idm] = 1;
+    }
+    if (touched) *flag = 1;                             // this wave's displaced plane is no longer zero: ONE write
 }
 
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a

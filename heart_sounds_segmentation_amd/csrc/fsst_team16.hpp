@@ -175,11 +175,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
     f2* disp_base = own_base + 16 * C::LD;
     int* flag = reinterpret_cast<int*>(disp_base + 16 * C::LDF);
-    int* tq = flag + 4;
+    int* tq = flag + kCanonFlagWords;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
     for (int i = lane; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-    if (lane < 4) flag[lane] = 0;
+    if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
     for (int i = threadIdx.x; i < 2 * MS; i += 64 * WPB) ready[i] = 0u;       // ready[], claim[]
