@@ -291,20 +291,30 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     // cost the plain path of the team kernel 4 %).  Interior groups: 32 constants per lane group from the first frame's copy in LDS; a group
     // at an end of the signal: left + right - interior of the per-frame tables in global memory (8 of a 2000-sample signal's 125 groups).
     if constexpr (OFFS) {
-        if (__builtin_expect(tile.mean_s != 0.0f, 0)) {
+        // (two sibling blocks, not one with two arms: the edge block's loads in flight made the register allocator spill two dozen of the
+        //  spectra's registers AROUND THE WHOLE offset block -- every interior group of an offset tile, 117 of a signal's 125, paid 48
+        //  scratch operations, 3 GB of scratch traffic per 1024 windows, most of what such a tile cost)
+        const bool off_interior = tile.mean_s != 0.0f && tg >= 64 && tg + 15 + 63 <= n - 1;      // (wave-uniform)
+        const bool off_edge = tile.mean_s != 0.0f && !off_interior;
+        if (__builtin_expect(off_interior, 0)) {         // interior: the constants' copy in LDS (broadcast reads)
+            int lane_f = lane_o;
+            asm volatile("" : "+v"(lane_f));
+            const int gq = (lane_f >> 4) & 3;
+            const f2 mm = {tile.mean_s, tile.mean_s};
+            const f2* zl = reinterpret_cast<const f2*>(atab + kCanonAtabFloats) + gq * kCanonYcGroup;
+            static_for<NT>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                za[i] = pk_fma(zl[i], mm, za[i]);
+                zb[i] = pk_fma(zl[NT + i], mm, zb[i]);
+            });
+        }
+        if (__builtin_expect(off_edge, 0)) {
             int lane_f = lane_o;
             asm volatile("" : "+v"(lane_f));
             const int gq = (lane_f >> 4) & 3;
             const f2 mm = {tile.mean_s, tile.mean_s};
             const f2* zg = reinterpret_cast<const f2*>(zc) + gq * kCanonYcGroup;
-            if (tg >= 64 && tg + 15 + 63 <= n - 1) {     // (wave-uniform) interior: the constants' copy in LDS (broadcast reads)
-                const f2* zl = reinterpret_cast<const f2*>(atab + kCanonAtabFloats) + gq * kCanonYcGroup;
-                static_for<NT>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    za[i] = pk_fma(zl[i], mm, za[i]);
-                    zb[i] = pk_fma(zl[NT + i], mm, zb[i]);
-                });
-            } else {
+            {
                 // a group at an end of the signal: the frame's own constants -- left-edge table by output column, right-edge table by samples
                 // to the end (both, less the interior, for a signal shorter than a window and a half).  Eight entries at a time: left alone
                 // the scheduler requests all of them first and spills the spectra.
