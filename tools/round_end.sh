@@ -1,11 +1,11 @@
 set -x
-python -m pytest tests -q -m gpu 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 > gpurun_out/r05e_gpu_pytest.txt
-bash tools/profile_round.sh r05e > /dev/null 2>&1
-timeout 300 python tools/input_cost.py > gpurun_out/r05e_input_cost.txt 2>&1
-timeout 1500 python tools/adversarial_parity.py 32 64 100 127 128 256 512 > gpurun_out/r05e_adversarial_parity.txt 2>&1; echo "rc $?" >> gpurun_out/r05e_adversarial_parity.txt
-timeout 600 python tools/fuzz_parity.py 600 5 > gpurun_out/r05e_fuzz_parity.txt 2>&1; echo "rc $?" >> gpurun_out/r05e_fuzz_parity.txt
-timeout 300 python tools/split_fold_census.py > gpurun_out/r05e_split_fold_census.txt 2>&1
-timeout 400 python tools/configs_bench.py > gpurun_out/r05e_configs.json 2> gpurun_out/r05e_configs.err
-timeout 300 python tools/batch_sweep.py > gpurun_out/r05e_batch_sweep.txt 2>&1
-cat gpurun_out/r05e_gpu_pytest.txt
-tail -3 gpurun_out/r05e_adversarial_parity.txt; tail -3 gpurun_out/r05e_fuzz_parity.txt; tail -3 gpurun_out/r05e_split_fold_census.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 > gpurun_out/r05f_gpu_pytest.txt
+bash tools/profile_round.sh r05f > /dev/null 2>&1
+timeout 300 python tools/input_cost.py > gpurun_out/r05f_input_cost.txt 2>&1
+timeout 1500 python tools/adversarial_parity.py 32 64 100 127 128 256 512 > gpurun_out/r05f_adversarial_parity.txt 2>&1; echo "rc $?" >> gpurun_out/r05f_adversarial_parity.txt
+timeout 600 python tools/fuzz_parity.py 600 5 > gpurun_out/r05f_fuzz_parity.txt 2>&1; echo "rc $?" >> gpurun_out/r05f_fuzz_parity.txt
+timeout 300 python tools/split_fold_census.py > gpurun_out/r05f_split_fold_census.txt 2>&1
+timeout 400 python tools/configs_bench.py > gpurun_out/r05f_configs.json 2> gpurun_out/r05f_configs.err
+timeout 300 python tools/batch_sweep.py > gpurun_out/r05f_batch_sweep.txt 2>&1
+cat gpurun_out/r05f_gpu_pytest.txt
+tail -3 gpurun_out/r05f_adversarial_parity.txt; tail -3 gpurun_out/r05f_fuzz_parity.txt; tail -3 gpurun_out/r05f_split_fold_census.txt
