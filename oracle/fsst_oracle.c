@@ -166,6 +166,119 @@ static double matlab_mod(double a, double n)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * What every window of one call shares (made once per call, read-only afterwards): derivative
+ * window, psdfreqvec, the modified-STFT phase factors and the DFT plan -- steps 3-5 below.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int N, nf, m; double fs; const double* w; double* dw; double* fk; double* ez; dft_plan plan; } fsst_setup;
+
+static void setup_free(fsst_setup* s)
+{
+    dft_plan_free(&s->plan);
+    free(s->dw); free(s->fk); free(s->ez);
+    s->dw = s->fk = s->ez = NULL;
+}
+
+static int setup_init(fsst_setup* s, const double* w, int N, double fs)
+{
+    s->N = N; s->nf = N / 2 + 1; s->m = N / 2; s->fs = fs; s->w = w;
+    s->plan.cs = NULL; s->plan.rev = NULL;
+    s->dw = (double*)malloc(sizeof(double) * (size_t)N);
+    s->fk = (double*)malloc(sizeof(double) * (size_t)N);
+    s->ez = (double*)malloc(sizeof(double) * 2 * (size_t)N);
+    if (!s->dw || !s->fk || !s->ez) { setup_free(s); return -2; }
+    if (dft_plan_init(&s->plan, N) != 0) { setup_free(s); return -2; }
+    if (hss_oracle_dtwin(w, N, fs, s->dw) != 0) { setup_free(s); return -3; }
+    {   /* psdfreqvec, two-sided */
+        const double res = fs / (double)N;
+        for (int k = 0; k < N; ++k) s->fk[k] = res * (double)k;
+        if ((N % 2) == 0) s->fk[N / 2] = fs / 2.0;
+        if (N > 1) s->fk[N - 1] = fs - res;
+    }
+    for (int k = 0; k < N; ++k) {
+        const double a = -2.0 * HSS_PI * (double)s->m * (double)k / (double)N;
+        s->ez[2 * k] = cos(a); s->ez[2 * k + 1] = sin(a);
+    }
+    return 0;
+}
+
+/* A thread's scratch, allocated once per thread and reused for every window it takes (round 5
+ * allocated three ~1 MB arrays per window inside the OpenMP loop: the figure it produced was the
+ * allocator's lock, VERDICT r05 "weak" 4).  `col` is ONE output column (nf complex sums). */
+typedef struct { double* buf; double* xp; double* col; float* fre; float* fim; } fsst_ws;
+
+static void ws_free(fsst_ws* q) { free(q->buf); free(q->xp); free(q->col); free(q->fre); free(q->fim); }
+
+static int ws_init(fsst_ws* q, int N, int nx, size_t nfeat)
+{
+    q->buf = (double*)malloc(sizeof(double) * 8 * (size_t)N);
+    q->xp = (double*)malloc(sizeof(double) * ((size_t)nx + (size_t)N));
+    q->col = (double*)malloc(sizeof(double) * 2 * (size_t)(N / 2 + 1));
+    q->fre = nfeat ? (float*)malloc(sizeof(float) * nfeat) : NULL;
+    q->fim = nfeat ? (float*)malloc(sizeof(float) * nfeat) : NULL;
+    if (!q->buf || !q->xp || !q->col || (nfeat && (!q->fre || !q->fim))) { ws_free(q); return -2; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * fsst_window: steps 1-7 of hss_oracle_fsst (below) for ONE signal whose samples already lie,
+ * promoted to double and zero-padded, in q->xp.  Every output column is accumulated in q->col in
+ * ascending source order k = 0..N-1 -- the order, and therefore the bits, of accumarray on the
+ * (row, time) matrix -- and then handed out: rows 0..nf-1 as doubles into s_re/s_im (row-major
+ * nf x nx, the layout of ssq.fsst's `s`), and/or rows klo..klo+K-1 rounded to float32 (the
+ * complex64 cast of synchrosqueeze.py:51) into q->fre/q->fim (row-major K x nx).
+ * ---------------------------------------------------------------------------------------------- */
+static void fsst_window(const fsst_setup* s, fsst_ws* q, int nx, double* s_re, double* s_im,
+                        int klo, int K, double* halfdist)
+{
+    const int N = s->N, nf = s->nf;
+    const double* w = s->w; const double* dw = s->dw; const double* fk = s->fk; const double* ez = s->ez;
+    const double* xp = q->xp;
+    double* buf = q->buf;
+    double* are = buf;         double* aim = buf + N;      /* window .* frame (imag = 0) */
+    double* vre = buf + 2 * N; double* vim = buf + 3 * N;
+    double* bre = buf + 4 * N; double* dre = buf + 5 * N;  /* dwindow .* frame */
+    double* dim_ = buf + 6 * N; double* zero = buf + 7 * N;
+    double* cre = q->col; double* cim = q->col + nf;
+    const double fmin = fk[0], fmax = fk[N - 1];
+    for (int j = 0; j < N; ++j) { aim[j] = 0.0; zero[j] = 0.0; }
+    for (int tt = 0; tt < nx; ++tt) {
+        for (int j = 0; j < N; ++j) { are[j] = w[j] * xp[tt + j]; bre[j] = dw[j] * xp[tt + j]; }   /* step 2 */
+        dft_exec(&s->plan, are, aim, vre, vim);           /* step 3 */
+        dft_exec(&s->plan, bre, zero, dre, dim_);
+        for (int k = 0; k < nf; ++k) { cre[k] = 0.0; cim[k] = 0.0; }
+        double mind = 0.5;
+        for (int k = 0; k < N; ++k) {                  /* steps 4-6, ascending k */
+            /* imag(Vd/V) by the textbook complex quotient */
+            const double den = vre[k] * vre[k] + vim[k] * vim[k];
+            double fc = -((dim_[k] * vre[k] - dre[k] * vim[k]) / den);
+            if (!isfinite(fc)) fc = 0.0;
+            const double finst = fk[k] + fc;
+            double coord;
+            if (N > 1) coord = (finst - fmin) * (double)(N - 1) / (fmax - fmin);
+            else coord = 0.0;
+            const double r = round(coord);
+            const int row = (int)matlab_mod(r, (double)N);
+            if (halfdist) {
+                const double fr = fabs(fabs(coord - floor(coord)) - 0.5);
+                if (fr < mind) mind = fr;
+            }
+            if (row < nf) {                                /* step 7 */
+                const double mr = vre[k] * ez[2 * k] - vim[k] * ez[2 * k + 1];   /* step 5 */
+                const double mi = vre[k] * ez[2 * k + 1] + vim[k] * ez[2 * k];
+                cre[row] += mr;
+                cim[row] += mi;
+            }
+        }
+        if (halfdist) halfdist[tt] = mind;
+        if (s_re) for (int k = 0; k < nf; ++k) { s_re[(size_t)k * nx + tt] = cre[k]; s_im[(size_t)k * nx + tt] = cim[k]; }
+        if (q->fre) for (int k = 0; k < K; ++k) {
+            q->fre[(size_t)k * nx + tt] = (float)cre[klo + k];
+            q->fim[(size_t)k * nx + tt] = (float)cim[klo + k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * hss_oracle_fsst: restates `s, f, t = ssq.fsst(x, fs, window)` (call site synchrosqueeze.py:48),
  * i.e. MATLAB [sst, f, t] = fsst(x, fs, window) for a real vector x:
  *   1. nfft = numel(window) = N;  pad x with floor(N/2) zeros in front, N-1-floor(N/2) behind;
@@ -189,76 +302,19 @@ int hss_oracle_fsst(const double* x, int nx, double fs, const double* w, int N,
                     double* s_re, double* s_im, double* f, double* t, double* halfdist)
 {
     if (!x || !w || !s_re || !s_im || nx < 1 || N < 1 || !(fs > 0.0)) return -1;
-    const int m = N / 2;
-    const int nf = N / 2 + 1;
-    int rc = 0;
-    double* dw = (double*)malloc(sizeof(double) * (size_t)N);
-    double* fk = (double*)malloc(sizeof(double) * (size_t)N);
-    double* ez = (double*)malloc(sizeof(double) * 2 * (size_t)N);
-    double* buf = (double*)malloc(sizeof(double) * 8 * (size_t)N);
-    double* xp = (double*)calloc((size_t)nx + (size_t)N, sizeof(double));
-    dft_plan plan; plan.cs = NULL; plan.rev = NULL;
-    if (!dw || !fk || !ez || !buf || !xp) { rc = -2; goto done; }
-    if (dft_plan_init(&plan, N) != 0) { rc = -2; goto done; }
-    if (hss_oracle_dtwin(w, N, fs, dw) != 0) { rc = -3; goto done; }
-
-    {   /* psdfreqvec, two-sided */
-        const double res = fs / (double)N;
-        for (int k = 0; k < N; ++k) fk[k] = res * (double)k;
-        if ((N % 2) == 0) fk[N / 2] = fs / 2.0;
-        if (N > 1) fk[N - 1] = fs - res;
-    }
-    for (int k = 0; k < N; ++k) {
-        const double a = -2.0 * HSS_PI * (double)m * (double)k / (double)N;
-        ez[2 * k] = cos(a); ez[2 * k + 1] = sin(a);
-    }
-    memcpy(xp + m, x, sizeof(double) * (size_t)nx);        /* step 1 */
-    if (f) for (int k = 0; k < nf; ++k) f[k] = fk[k];
+    fsst_setup su;
+    fsst_ws q;
+    int rc = setup_init(&su, w, N, fs);
+    if (rc != 0) return rc;
+    if (ws_init(&q, N, nx, 0) != 0) { setup_free(&su); return -2; }
+    memset(q.xp, 0, sizeof(double) * ((size_t)nx + (size_t)N));
+    memcpy(q.xp + su.m, x, sizeof(double) * (size_t)nx);        /* step 1 */
+    if (f) for (int k = 0; k < su.nf; ++k) f[k] = su.fk[k];
     if (t) for (int j = 0; j < nx; ++j) t[j] = (double)j / fs;
-    memset(s_re, 0, sizeof(double) * (size_t)nf * (size_t)nx);
-    memset(s_im, 0, sizeof(double) * (size_t)nf * (size_t)nx);
-
-    {
-        double* are = buf;         double* aim = buf + N;      /* window .* frame (imag = 0) */
-        double* vre = buf + 2 * N; double* vim = buf + 3 * N;
-        double* bre = buf + 4 * N; double* dre = buf + 5 * N;  /* dwindow .* frame */
-        double* dim_ = buf + 6 * N; double* zero = buf + 7 * N;
-        const double fmin = fk[0], fmax = fk[N - 1];
-        for (int j = 0; j < N; ++j) { aim[j] = 0.0; zero[j] = 0.0; }
-        for (int tt = 0; tt < nx; ++tt) {
-            for (int j = 0; j < N; ++j) { are[j] = w[j] * xp[tt + j]; bre[j] = dw[j] * xp[tt + j]; }
-            dft_exec(&plan, are, aim, vre, vim);           /* step 3 */
-            dft_exec(&plan, bre, zero, dre, dim_);
-            double mind = 0.5;
-            for (int k = 0; k < N; ++k) {                  /* steps 4-6, ascending k */
-                /* imag(Vd/V) by the textbook complex quotient */
-                const double den = vre[k] * vre[k] + vim[k] * vim[k];
-                double fc = -((dim_[k] * vre[k] - dre[k] * vim[k]) / den);
-                if (!isfinite(fc)) fc = 0.0;
-                const double finst = fk[k] + fc;
-                double coord;
-                if (N > 1) coord = (finst - fmin) * (double)(N - 1) / (fmax - fmin);
-                else coord = 0.0;
-                const double r = round(coord);
-                const int row = (int)matlab_mod(r, (double)N);
-                if (halfdist) {
-                    const double fr = fabs(fabs(coord - floor(coord)) - 0.5);
-                    if (fr < mind) mind = fr;
-                }
-                if (row < nf) {
-                    const double mr = vre[k] * ez[2 * k] - vim[k] * ez[2 * k + 1];   /* step 5 */
-                    const double mi = vre[k] * ez[2 * k + 1] + vim[k] * ez[2 * k];
-                    s_re[(size_t)row * nx + tt] += mr;
-                    s_im[(size_t)row * nx + tt] += mi;
-                }
-            }
-            if (halfdist) halfdist[tt] = mind;
-        }
-    }
-    rc = nf;
-done:
-    dft_plan_free(&plan);
-    free(dw); free(fk); free(ez); free(buf); free(xp);
+    fsst_window(&su, &q, nx, s_re, s_im, 0, 0, halfdist);
+    rc = su.nf;
+    ws_free(&q);
+    setup_free(&su);
     return rc;
 }
 
@@ -297,68 +353,78 @@ int hss_oracle_band(int N, double fs, double f_lo, double f_hi, int* klo)
  * Statistics are accumulated in double and rounded to float32 (torch reduces in float32 with a
  * cascade; the two agree to ~1e-7 relative, far inside the 1e-4 gate).
  * `halfdist` optional (batch*nx), see hss_oracle_fsst.  nthreads <= 1: serial; else OpenMP over
- * windows.  Returns 0 on success.
+ * windows: the call's constants (fsst_setup) are made once, a thread's scratch (fsst_ws: two K x nx
+ * float32 planes + one column) once per thread -- nothing is allocated per window.  Returns 0 on success.
  * ---------------------------------------------------------------------------------------------- */
 int hss_oracle_features(const float* x, int64_t batch, int nx, double fs, const double* w, int N,
                         int has_band, double f_lo, double f_hi, int mode,
                         float* out, double* halfdist, int nthreads)
 {
-    if (!x || !w || !out || batch < 0 || nx < 1 || N < 1 || mode < 0 || mode > 2) return -1;
+    if (!x || !w || !out || batch < 0 || nx < 1 || N < 1 || mode < 0 || mode > 2 || !(fs > 0.0)) return -1;
     const int nf = N / 2 + 1;
     int klo = 0, K = nf;
     if (has_band) K = hss_oracle_band(N, fs, f_lo, f_hi, &klo);
     const size_t per = (mode == 1) ? (size_t)nx * K : (size_t)nx * K * 2;
-    int err = 0;
-#ifdef _OPENMP
+    const size_t nfeat = (size_t)nx * (size_t)K;
+    fsst_setup su;
+    int err = setup_init(&su, w, N, fs);
+    if (err != 0) return err;
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
 #endif
-    for (int64_t b = 0; b < batch; ++b) {
-        double* xd = (double*)malloc(sizeof(double) * (size_t)nx);
-        double* sre = (double*)malloc(sizeof(double) * (size_t)nf * nx);
-        double* sim = (double*)malloc(sizeof(double) * (size_t)nf * nx);
-        if (!xd || !sre || !sim) { err = -2; free(xd); free(sre); free(sim); continue; }
-        for (int j = 0; j < nx; ++j) xd[j] = (double)x[(size_t)b * nx + j];
-        const int r = hss_oracle_fsst(xd, nx, fs, w, N, sre, sim, NULL, NULL,
-                                      halfdist ? halfdist + (size_t)b * nx : NULL);
-        if (r < 0) { err = r; free(xd); free(sre); free(sim); continue; }
-        float* o = out + (size_t)b * per;
-        if (mode == 0) {
-            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
-                o[((size_t)k * nx + j) * 2 + 0] = (float)sre[(size_t)(klo + k) * nx + j];
-                o[((size_t)k * nx + j) * 2 + 1] = (float)sim[(size_t)(klo + k) * nx + j];
-            }
-        } else if (mode == 1) {
-            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
-                const float re = (float)sre[(size_t)(klo + k) * nx + j];
-                const float im = (float)sim[(size_t)(klo + k) * nx + j];
-                o[(size_t)j * K + k] = hypotf(re, im);
-            }
-        } else {
-            const double cnt = (double)K * (double)nx;
-            double sr = 0.0, si = 0.0;
-            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
-                sr += (double)(float)sre[(size_t)(klo + k) * nx + j];
-                si += (double)(float)sim[(size_t)(klo + k) * nx + j];
-            }
-            const double mr = sr / cnt, mi = si / cnt;
-            double qr = 0.0, qi = 0.0;
-            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
-                const double dr = (double)(float)sre[(size_t)(klo + k) * nx + j] - mr;
-                const double di = (double)(float)sim[(size_t)(klo + k) * nx + j] - mi;
-                qr += dr * dr; qi += di * di;
-            }
-            const float mean_r = (float)mr, mean_i = (float)mi;
-            const float std_r = (float)sqrt(qr / (cnt - 1.0)), std_i = (float)sqrt(qi / (cnt - 1.0));
-            for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
-                const float re = (float)sre[(size_t)(klo + k) * nx + j];
-                const float im = (float)sim[(size_t)(klo + k) * nx + j];
-                o[(size_t)j * 2 * K + k] = (re - mean_r) / std_r;
-                o[(size_t)j * 2 * K + K + k] = (im - mean_i) / std_i;
+    {
+        fsst_ws q;
+        const int have = ws_init(&q, N, nx, nfeat ? nfeat : 1);
+        if (have != 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = -2;
+        }
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int64_t b = 0; b < batch; ++b) {
+            if (have != 0) continue;
+            memset(q.xp, 0, sizeof(double) * ((size_t)nx + (size_t)N));
+            for (int j = 0; j < nx; ++j) q.xp[su.m + j] = (double)x[(size_t)b * nx + j];   /* :48 promotes; step 1 */
+            fsst_window(&su, &q, nx, NULL, NULL, klo, K, halfdist ? halfdist + (size_t)b * nx : NULL);
+            const float* fre = q.fre; const float* fim = q.fim;
+            float* o = out + (size_t)b * per;
+            if (mode == 0) {
+                for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                    o[((size_t)k * nx + j) * 2 + 0] = fre[(size_t)k * nx + j];
+                    o[((size_t)k * nx + j) * 2 + 1] = fim[(size_t)k * nx + j];
+                }
+            } else if (mode == 1) {
+                for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j)
+                    o[(size_t)j * K + k] = hypotf(fre[(size_t)k * nx + j], fim[(size_t)k * nx + j]);
+            } else {
+                const double cnt = (double)K * (double)nx;
+                double sr = 0.0, si = 0.0;
+                for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                    sr += (double)fre[(size_t)k * nx + j];
+                    si += (double)fim[(size_t)k * nx + j];
+                }
+                const double mr = sr / cnt, mi = si / cnt;
+                double qr = 0.0, qi = 0.0;
+                for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                    const double dr = (double)fre[(size_t)k * nx + j] - mr;
+                    const double di = (double)fim[(size_t)k * nx + j] - mi;
+                    qr += dr * dr; qi += di * di;
+                }
+                const float mean_r = (float)mr, mean_i = (float)mi;
+                const float std_r = (float)sqrt(qr / (cnt - 1.0)), std_i = (float)sqrt(qi / (cnt - 1.0));
+                for (int k = 0; k < K; ++k) for (int j = 0; j < nx; ++j) {
+                    o[(size_t)j * 2 * K + k] = (fre[(size_t)k * nx + j] - mean_r) / std_r;
+                    o[(size_t)j * 2 * K + K + k] = (fim[(size_t)k * nx + j] - mean_i) / std_i;
+                }
             }
         }
-        free(xd); free(sre); free(sim);
+        if (have == 0) ws_free(&q);
     }
+    setup_free(&su);
     return err;
 }
 
