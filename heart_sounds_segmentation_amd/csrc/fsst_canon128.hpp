@@ -43,8 +43,7 @@ constexpr int kCanonAtabFloats = kCanonOpFloats + 4 * 128;   // + {cos, sin}(2 p
 constexpr int kCanonLdsTabFloats = kCanonAtabFloats + 4 * 33 * 2;   // what the kernels keep in LDS: + the interior frame of the offset table ("Offsets"), 1 kB
 constexpr int kCanonErrMul = 4;                          // tau^2 of the rounding-tie bound: 4 kTieErr2 (tau = 2e-6 (1 + |shift|) R / |V|)
 // (rounding ties: the bitmap of fsst_mfma128.hpp, "Rounding ties"; the float64 path reads the signal's own samples)
-constexpr int kCanonFlagWords = 8;                       // [0] the displaced plane is dirty [1] the tie bitmap has a bit [2..7] one BYTE per column of the
-                                                         // displaced plane that was added to (canon_displaced -> move_source<COLS>; the fold looks at those)
+constexpr int kCanonFlagWords = 8;                       // [1] the tie bitmap has a bit (the others: spare)
 constexpr int kCanonTieWords = 32;                       // [0..31] bitmap (flag[1] = "some bit is set")
 
 template <int KLO, int KC>
@@ -91,7 +90,8 @@ struct CanonCfg {
         return (nd <= 1 ? 0.5f : static_cast<float>(nd) - 0.5f) - static_cast<float>(1 + (nd <= 1 ? 0 : nd)) * kTieMargin;
 #endif
     }
-    static constexpr int wave_floats() { return 2 * kCanonRecs + 2 * 16 * (LD + LDF) + kCanonFlagWords + kCanonTieWords; }
+    static_assert(KLO >= 1, "row 0 is its own twin: acc_source / canon_put want the band above it");
+    static constexpr int wave_floats(int planes = 1) { return 2 * kCanonRecs + planes * 2 * 16 * LD + kCanonFlagWords + kCanonTieWords; }
 };
 
 // Host side of the f16 operand table: entry (tap n, lane l, half h): lane l = (kk, row i); h -> fold term q = kk + 4 (h >> 2),
@@ -191,11 +191,21 @@ __device__ __forceinline__ CanonTile canon_land(const float (&sreg)[3], u2* xrec
     return stage(sreg, te.E, te.E, 0.0f);
 }
 
-// Rare path of a displaced source (oracle/fsst_oracle.c steps 4-6 in float32), as displaced_source of fsst_mfma128.hpp
-// with the bitmap instead of the queues.  `row_disp` = this lane's frame row of the displaced plane.
-template <int KLO, int KC>
-__device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigned* tb, int kpi, int j, float num, float den, f2 V,
-                                                float R2, float eoff, f2* own_cell, bool stored)
+// One plane.  Rounds 1-4 kept two planes per wave: the own plane, into which every source stores its V, and a displaced plane that
+// collected the sources that move (atomic adds), folded into the own plane and cleared after the source stage -- 47 kB of LDS that is
+// zero between groups.  The additions now go into the own plane ITSELF.  What the second plane was for is order: a cell must have its
+// owner's store -- unconditional, in stripe order -- before anything is added to it, and must not be cleared after.  So, per stripe,
+// the rare path (i) decides both classes, (ii) clears the own cells of the sources that leave -- movers and undecided ones alike: an
+// undecided source is added by the float64 path, from the float64 V, wherever it belongs --, (iii) adds: at once into rows of stripes
+// that are stored already (its own and lower ones: every downward and most upward moves), while a destination in a HIGHER stored
+// stripe -- a source in the last row of its stripe moving up -- only sets the lane's bit, and those few sources are redone
+// behind the last stored stripe from the spectra (still in registers).  Every cell receives its contributions in program order,
+// as before; a cell with two or more of them may differ in the last bit from the two-plane kernels' own + (d1 + d2).
+// What the second plane's LDS buys: fsst_team16.hpp.
+//
+// Decision of a displaced source in float32 (oracle/fsst_oracle.c steps 4-5), as displaced_source of fsst_mfma128.hpp.
+struct CanonMove { int row; bool tie; };                 // destination row 0 .. nwin - 1; undecided in float32
+__device__ __forceinline__ CanonMove canon_decide(int kpi, float num, float den, float R2, float eoff)
 {
     constexpr int NWIN = 128;
     float shift = num * __builtin_amdgcn_rcpf(den);
@@ -204,25 +214,45 @@ __device__ __forceinline__ void canon_displaced(f2* row_disp, int* flag, unsigne
     float fr = a - floorf(a) - 0.5f;
     const float s1 = 1.0f + fabsf(shift);
     asm volatile("" : "+v"(fr));                        // (see displaced_source: keeps the two product chains unpacked)
+    CanonMove m;
 #ifndef HSS_NO_TIES
-    if (fr * fr * den < (kTieErr2 * kCanonErrMul) * s1 * s1 * fmaf(eoff, den, R2) && den > kTieFloor2 * R2) {     // too close to call in float32
-        __hip_atomic_fetch_or(tb + (kpi >> 1), 1u << (((kpi & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        flag[1] = 1;
-        return;
-    }
+    m.tie = fr * fr * den < (kTieErr2 * kCanonErrMul) * s1 * s1 * fmaf(eoff, den, R2) && den > kTieFloor2 * R2;     // too close to call in float32
+#else
+    m.tie = false;
 #endif
     const float r = truncf(a + copysignf(0.5f, a));     // MATLAB round: half away from zero
-    move_source<NWIN, true, false, true>(row_disp, flag, KLO, KC, kpi, static_cast<int>(r) & (NWIN - 1), V, own_cell, stored);
+    m.row = static_cast<int>(r) & (NWIN - 1);
+    return m;
+}
+// The addition of a source of stripe S that moves to `row` (oracle step 6: the row, or the twin's for a source that wraps around row 0).
+// Returns true when the destination lies in a stored stripe ABOVE S -- not stored yet: the caller redoes the source later ("One plane").
+// `row0` = this lane's frame row of the plane, indexed by spectrum row.
+template <int KLO, int KC, int S>
+__device__ __forceinline__ bool canon_put(f2* row0, int kpi, int row, f2 V)
+{
+    constexpr int NWIN = 128;
+    int t = row;
+    float vy = V.y;
+    if (!(static_cast<unsigned>(row - KLO) < static_cast<unsigned>(KC))) {
+        if (!(row > NWIN / 2 && kpi != 0)) return false;
+        t = NWIN - row; vy = -V.y;                       // negative-frequency twin: row -> nwin - row, value conj
+        if (!(static_cast<unsigned>(t - KLO) < static_cast<unsigned>(KC))) return false;
+    }
+    if (S < 3 && (t >> 3) > S) return true;              // (the band lies in stripes 0..3)
+    float* q = reinterpret_cast<float*>(row0 + t);
+    __hip_atomic_fetch_add(q, V.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q + 1, vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return false;
 }
 
 // The group's transform up to and including the scatter: on return the own plane [16][LD] holds the group's synchrosqueezed
-// rows COV0 .. (scaled by the tile's power of two), displaced cells folded in, tie queues resolved and cleared.
+// rows COV0 .. (scaled by the tile's power of two), displaced cells added, the tie bitmap resolved and cleared.
 // xrec = the group's first frame in the tile's records; atab = the shared operand table in LDS; (xsig, n, tg) = the signal and
 // the group's first output column, for the float64 tie path.
 // (xsig: the signal's samples for the float64 rounding-tie path -- a pointer, or a callable that makes it: a kernel whose signal base is
 //  a 64-bit product per group hands over the recipe and pays for it in the rare path only)
 template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*>
-__device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, f2* disp_base, int* flag, int* tq,
+__device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
                                             XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
 {
@@ -381,7 +411,8 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     asm volatile("" : "+v"(oa), "+v"(ob));
     lds_float* ownA = (lds_float*)static_cast<size_t>(oa);
     lds_float* ownB = (lds_float*)static_cast<size_t>(ob);
-    f2* row_disp = disp_base + j * C::LDF;
+    f2* row0 = own_base + j * C::LD - C::COV0;           // this lane's frame row of the plane, indexed by spectrum row (rare path)
+    unsigned defer = 0u;                                 // bit 2 s + class: a source of stripe s <= 2 whose destination was not stored yet ("One plane")
     float mx = 0.0f;                                     // largest |V|^2 among this lane's stored cells ("Exact groups")
     bool visited = false;                                // (wave-uniform) some stripe took the rare path: only then are the flags in LDS worth a look
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 4
@@ -412,18 +443,51 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
 #endif
             f2* cellA = reinterpret_cast<f2*>((float*)(ownA + 16 * s));
             f2* cellB = reinterpret_cast<f2*>((float*)(ownB + 16 * s));
-            if (ma) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rAi + RQ * s, j, dna.y, dna.x, f2{a1.x, a2.x}, tile.R2s, tile.eoff(), cellA, STA);
-            if (mb) canon_displaced<KLO, KC>(row_disp, flag, reinterpret_cast<unsigned*>(tq), rBi + RQ * s, j, dnb.y, dnb.x, f2{b1.x, b2.x}, tile.R2s, tile.eoff(), cellB, STB);
+            const int kA = rAi + RQ * s, kB = rBi + RQ * s;
+            unsigned* tb = reinterpret_cast<unsigned*>(tq);
+            // ("One plane") (i) decide both classes ...
+            CanonMove da{kA, false}, db{kB, false};
+            if (ma) da = canon_decide(kA, dna.y, dna.x, tile.R2s, tile.eoff());
+            if (mb) db = canon_decide(kB, dnb.y, dnb.x, tile.R2s, tile.eoff());
+            const bool la = ma && (da.tie || da.row != kA), lb = mb && (db.tie || db.row != kB);      // leaves its own cell
+            // ... (ii) undecided sources set their bits, every source that leaves clears its cell ...
+            if (ma && da.tie) { __hip_atomic_fetch_or(tb + (kA >> 1), 1u << (((kA & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); flag[1] = 1; }
+            if (mb && db.tie) { __hip_atomic_fetch_or(tb + (kB >> 1), 1u << (((kB & 1) << 4) + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); flag[1] = 1; }
+            if constexpr (STA) { if (la) *cellA = f2{0.0f, 0.0f}; }
+            if constexpr (STB) { if (lb) *cellB = f2{0.0f, 0.0f}; }
+            // ... (iii) and the movers add
+            if (la && !da.tie) { if (canon_put<KLO, KC, s>(row0, kA, da.row, f2{a1.x, a2.x})) defer |= 1u << (2 * s); }
+            if (lb && !db.tie) { if (canon_put<KLO, KC, s>(row0, kB, db.row, f2{b1.x, b2.x})) defer |= 1u << (2 * s + 1); }
+        }
+        if constexpr (s == 3) {
+            // ("One plane") the sources of stripes 0..2 whose destination lay in a stripe that had not been stored yet: redone from the
+            // spectra, decision and all (the same arithmetic on the same numbers), now that every stored stripe is there
+            if (__builtin_expect(visited && __builtin_amdgcn_ballot_w64(defer != 0u) != 0ull, 0)) {
+                static_for<3>([&](auto TT) {
+                    constexpr int t = decltype(TT)::value;
+                    if (__builtin_amdgcn_ballot_w64((defer >> (2 * t)) & 3u) != 0ull) {
+                        const f2 QA = zb[NT - 1 - t], QB = za[NT - 1 - t];
+                        const f2 c1 = mix_re(za[t], QA), c2 = mix_im(za[t], QA), e1 = mix_re(zb[t], QB), e2 = mix_im(zb[t], QB);
+                        const f2 dc = dn_second(c2, dn_first(c1, tiny)), de = dn_second(e2, dn_first(e1, tiny));
+                        if ((defer >> (2 * t)) & 1u) {
+                            const CanonMove d = canon_decide(rAi + RQ * t, dc.y, dc.x, tile.R2s, tile.eoff());
+                            (void)canon_put<KLO, KC, 3>(row0, rAi + RQ * t, d.row, f2{c1.x, c2.x});
+                        }
+                        if ((defer >> (2 * t + 1)) & 1u) {
+                            const CanonMove d = canon_decide(rBi + RQ * t, de.y, de.x, tile.R2s, tile.eoff());
+                            (void)canon_put<KLO, KC, 3>(row0, rBi + RQ * t, d.row, f2{e1.x, e2.x});
+                        }
+                    }
+                });
+            }
         }
     });
     CPROBE(2);
     wave_sync();
-    // the per-group flags (the displaced plane is dirty; the tie bitmap has a bit) are set by the rare path only: a group that never went
-    // there skips the trip to LDS and its wait.  One round trip for both (the empty statement keeps
-    // the compiler from sinking the second read behind the first branch).
-    int f_dirty = 0, f_ties = 0;
-    if (visited) { f_dirty = flag[0]; f_ties = flag[1]; }
-    asm volatile("" : "+v"(f_dirty), "+v"(f_ties));
+    // the tie flag is set by the rare path only: a group that never went there skips the trip to LDS and its wait
+    int f_ties = 0;
+    if (visited) f_ties = flag[1];
+    asm volatile("" : "+v"(f_ties));
     auto signal_sample = [&](int i) -> double {
         const int gi = tg + i - NWIN / 2;
         const float* xs;
@@ -449,37 +513,21 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     }
 #endif
     if (__builtin_expect(exact, 0)) {
-        for (int i = lane_o; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
-        if (lane_o < 2) flag[lane_o] = 0;
+        // (the float32 contributions are dropped: every cell of the group comes from the float64 pass)
+        for (int i = lane_o; i < 16 * C::LD; i += 64) own_base[i] = f2{0.0f, 0.0f};
+        if (lane_o == 0) flag[1] = 0;
         wave_sync();
-        resolve_bitmap<NWIN, true, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD,
-                                         C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
+        resolve_bitmap<NWIN, true, true, true>(reinterpret_cast<unsigned*>(tq), signal_sample, own_base, C::LD, flag, KLO, KC, own_base, C::LD,
+                                               C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
-        f_dirty = flag[0] != 0 ? -1 : 0;                 // (the float64 pass does not say which columns it added to)
         HSS_RARE_VMEM_DONE();
     } else
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(f_ties) != 0, 0)) {       // (rare) cells whose rounding float32 cannot decide
         // the float64 DFT reads the signal itself (HBM / L2): the records hold 22 bits of a sample, and a coordinate that is
         // 1e-5 bins from a half-integer needs all 24
-        resolve_bitmap<NWIN, false, true>(reinterpret_cast<unsigned*>(tq), signal_sample, disp_base, C::LDF, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
+        resolve_bitmap<NWIN, false, true, true>(reinterpret_cast<unsigned*>(tq), signal_sample, own_base, C::LD, flag, KLO, KC, own_base, C::LD, C::COV0, C::COV0 + C::COVN, wtab, tw_lds, 1.0 / static_cast<double>(tile.inv), lane_o);
         wave_sync();
-        f_dirty = flag[0] != 0 ? -1 : 0;
         HSS_RARE_VMEM_DONE();
-    }
-    if (__builtin_amdgcn_readfirstlane(f_dirty) != 0) {      // (rare) fold the displaced plane into the own plane, clear it
-        // (flag[2..7] hold one byte per column that was added to -- canon_displaced / move_source<COLS>: a plain byte store per moving lane;
-        //  an atomic OR into one word serialised the lanes and cost a tile in which every cell moves a fifth of its time --: lane group g
-        //  folds columns g + 4 u, and a quad of columns that nothing was added to -- word u is zero -- is not looked at: most dirty groups
-        //  have one or two, and the whole fold is 30 LDS operations.  A float64 pass does not say where it added: all of them.)
-        const bool all = __builtin_amdgcn_readfirstlane(f_dirty) == -1;
-        int cw = (lane_o < 6) ? flag[2 + lane_o] : 0;
-        f2* src = own_base + j * C::LD + C::KOFF + g;
-        f2* dsp = disp_base + j * C::LDF + g;
-#pragma unroll
-        for (int u = 0; u < 6; ++u)
-            if (4 * u < KC && (all || __builtin_amdgcn_readlane(cw, u) != 0) && g + 4 * u < KC) { src[4 * u] += dsp[4 * u]; dsp[4 * u] = f2{0.0f, 0.0f}; }
-        if (lane_o < kCanonFlagWords && lane_o != 1) flag[lane_o] = 0;
-        wave_sync();
     }
     CPROBE(3);
 #undef CPROBE
@@ -631,13 +679,11 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
     float* wbase = smem + ATAB + CTL + wv * C::wave_floats();
     u2* xrec = reinterpret_cast<u2*>(wbase);
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
-    f2* disp_base = own_base + 16 * C::LD;
-    int* flag = reinterpret_cast<int*>(disp_base + 16 * C::LDF);
+    int* flag = reinterpret_cast<int*>(own_base + 16 * C::LD);
     int* tq = flag + kCanonFlagWords;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
     const int ncols = p.ncols, cend = p.col0 + p.ncols;
-    for (int i = lane; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < (FUSED ? 8 : 1)) next_q[threadIdx.x] = 0;
@@ -805,7 +851,7 @@ __global__ __launch_bounds__(64 * 16, HSS_MW128) void fsst_canon_kernel(CanonPar
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int tg = p.col0 + gidx * 16;
-            canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, disp_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg, p.atab + kCanonAtabFloats);
+            canon_group<KLO, KC>(xrec + (gidx + cg0 - tbase) * 16, atab, own_base, flag, tq, p.wtab, p.twtab, tile, tiny, lane_o, xsig, n, tg, p.atab + kCanonAtabFloats);
             const int nvalid = min(16, cend - tg);
 #if defined(HSS_CANON_ABLATE) && HSS_CANON_ABLATE >= 2
             if (p.mode == 77) {

@@ -382,6 +382,26 @@ __device__ __forceinline__ void move_source(f2* row_disp, int* flag, int klo, in
     if (touched) *flag = 1;                             // this wave's displaced plane is no longer zero: ONE write
 }
 
+// The move for a plane that takes the displaced additions ITSELF (fsst_canon128.hpp, "One plane"; bands inside rows 1 .. nwin/2 - 1): the
+// source's own cell has been cleared by whoever found it moving, V is added at `row` (its own row included: it "rounds back") or, for a
+// source that wraps around row 0, conjugated at the twin's.  `row0` = this frame's row of the plane, indexed by spectrum row.
+template <int NWIN>
+__device__ __forceinline__ void acc_source(f2* row0, int klo, int K, int kpi, int row, f2 V)
+{
+    if (static_cast<unsigned>(row - klo) < static_cast<unsigned>(K)) {
+        float* q = reinterpret_cast<float*>(row0 + row);
+        __hip_atomic_fetch_add(q, V.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(q + 1, V.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (row > NWIN / 2 && kpi != 0) {
+        const int idm = NWIN - row;                      // negative-frequency twin: row -> nwin - row, value conj
+        if (static_cast<unsigned>(idm - klo) < static_cast<unsigned>(K)) {
+            float* q = reinterpret_cast<float*>(row0 + idm);
+            __hip_atomic_fetch_add(q, V.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(q + 1, -V.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // Rare path for a displaced source: oracle/fsst_oracle.c steps 4-6 in fp32, except for coordinates too close to a
 // rounding tie, which are queued for resolve_ties().  `row_disp` points at this lane's frame row (frame j of the
 // group) in the displaced plane.
@@ -418,7 +438,9 @@ __device__ __forceinline__ void displaced_source(f2* row_disp, int* flag, int* t
 // DFT's, times the plane's sign (-1)^k' (even nwin: the modified-STFT phase) and `plane_scale` (1 unless the plane holds
 // scaled values, fsst_canon128.hpp).
 // REFRESH (the exact mode of a group, see "Exact groups" below): the own cell is first rewritten with the float64 value.
-template <int NWIN, bool REFRESH = false>
+// ACC: the own plane takes the additions itself and holds nothing of an undecided source (its cell was cleared when it was found
+// undecided: fsst_canon128.hpp, "One plane"): V is the float64 DFT's, rounded once, added where it belongs -- its own row included.
+template <int NWIN, bool REFRESH = false, bool ACC = false>
 __device__ __forceinline__ void resolve_one(f2* disp_base, int LDF, int* flag, int klo, int K, f2* own_base, int OLD, int cov0, int cov1,
                                             int kpi, int jf, double vr, double vi, double dr, double di, double plane_scale)
 {
@@ -429,6 +451,10 @@ __device__ __forceinline__ void resolve_one(f2* disp_base, int LDF, int* flag, i
     const double r = (a >= 0.0) ? floor(a + 0.5) : -floor(0.5 - a);
     const int row = static_cast<int>(static_cast<long long>(r)) & (NWIN - 1);
     const double sg = (kpi & 1) ? -plane_scale : plane_scale;
+    if constexpr (ACC) {
+        acc_source<NWIN>(own_base + jf * OLD - cov0, klo, K, kpi, row, f2{static_cast<float>(vr * sg), static_cast<float>(vi * sg)});
+        return;
+    }
     if (kpi >= cov0 && kpi < cov1) {
         f2* cell = own_base + jf * OLD + (kpi - cov0);
         f2 V;
@@ -569,7 +595,7 @@ __device__ __forceinline__ void resolve_group_f64(const unsigned* tb, Sample sam
 
 // nwin = 128 (16 taps, radix 8, one stripe per pass, samples in registers): the same, written out for the 128-register kernels
 // -- the general form above needs a few registers more than they have.
-template <bool REFRESH, bool TWLDS, class Sample>
+template <bool REFRESH, bool TWLDS, bool ACC = false, class Sample>
 __device__ __forceinline__ void resolve_group_f64_128(const unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
                                                   f2* own_base, int OLD, int cov0, int cov1, const double* a64, const double* twtab,
                                                   double plane_scale, int lane)
@@ -613,16 +639,16 @@ __device__ __forceinline__ void resolve_group_f64_128(const unsigned* tb, Sample
         // plane values (-1)^k' V = X + conj(P), (-1)^k' Vd' = (X - conj(P)) / i; resolve_one takes V, Vd' themselves
         const double sa = (ka & 1) ? -1.0 : 1.0, sb = (kb & 1) ? -1.0 : 1.0;
         if (flagged(ka))
-            resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, ka, j,
+            resolve_one<NWIN, REFRESH, ACC>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, ka, j,
                                        sa * (xa[0] + par), sa * (xa[1] - pai), sa * (xa[1] + pai), sa * (par - xa[0]), plane_scale);
         if (flagged(kb))
-            resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kb, j,
+            resolve_one<NWIN, REFRESH, ACC>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kb, j,
                                        sb * (xb[0] + pbr), sb * (xb[1] - pbi), sb * (xb[1] + pbi), sb * (pbr - xb[0]), plane_scale);
     }
 }
 
 constexpr int kTieGroup64 = 24;              // nwin = 128: from this many undecided cells on the group is redone by resolve_group_f64
-template <int NWIN, bool REFRESH = false, bool TWLDS = false, class Sample>
+template <int NWIN, bool REFRESH = false, bool TWLDS = false, bool ACC = false, class Sample>
 __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* disp_base, int LDF, int* flag, int klo, int K,
                                                f2* own_base, int OLD, int cov0, int cov1,
                                                const double* wtab, const double* twtab, double plane_scale, int lane_in)
@@ -644,7 +670,7 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
             constexpr int NT = NWIN == 512 ? 32 : 16, RQ = NWIN / NT;
             constexpr int SPP = NWIN == 128 ? 1 : 4;
             if constexpr (NWIN == 128)
-                resolve_group_f64_128<REFRESH, TWLDS>(tb, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, wtab + 4 * NWIN, twtab,
+                resolve_group_f64_128<REFRESH, TWLDS, ACC>(tb, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, wtab + 4 * NWIN, twtab,
                                                       plane_scale, lane);
             else
                 resolve_group_f64<NT, RQ, SPP, false, REFRESH, TWLDS>(tb, sample, disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1,
@@ -700,7 +726,7 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
                     vr += shfl_xor_f64(vr, off, lane); vi += shfl_xor_f64(vi, off, lane);
                     dr += shfl_xor_f64(dr, off, lane); di += shfl_xor_f64(di, off, lane);
                 }
-                if (lane == 0) resolve_one<NWIN>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
+                if (lane == 0) resolve_one<NWIN, false, ACC>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
             }
         } else {
             // many cells (tonal or offset-dominated signals under low-sidelobe windows): lane l owns source k' = k0 + l, and
@@ -739,7 +765,7 @@ __device__ __forceinline__ void resolve_bitmap(unsigned* tb, Sample sample, f2* 
                         dr = fma(b, cs.x, dr); di = fma(-b, cs.y, di);
                     }
                 }
-                if ((hw >> jf) & 1u) resolve_one<NWIN, REFRESH>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
+                if ((hw >> jf) & 1u) resolve_one<NWIN, REFRESH, ACC>(disp_base, LDF, flag, klo, K, own_base, OLD, cov0, cov1, kpi, jf, vr, vi, dr, di, plane_scale);
             }
         }
         if (lane < 32) tbs[lane] = 0u;

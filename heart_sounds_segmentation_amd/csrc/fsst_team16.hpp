@@ -173,12 +173,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS, MS) + wv * C::wave_floats();
     u2* xrec = reinterpret_cast<u2*>(wbase);
     f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
-    f2* disp_base = own_base + 16 * C::LD;
-    int* flag = reinterpret_cast<int*>(disp_base + 16 * C::LDF);
+    int* flag = reinterpret_cast<int*>(own_base + 16 * C::LD);
     int* tq = flag + kCanonFlagWords;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
-    for (int i = lane; i < 16 * C::LDF; i += 64) disp_base[i] = f2{0.0f, 0.0f};
     if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
@@ -461,7 +459,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
-        canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, disp_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
+        canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
                                            [&]() -> const float* { return P()->x + static_cast<unsigned long long>(b) * static_cast<unsigned>(P()->xstride); }, n, tg, P()->atab + kCanonAtabFloats);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
