@@ -81,8 +81,14 @@ constexpr int t16_ctl_base(int slots) { return 16 + 64 + 192 + 2 * slots + kT16S
 // ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
 constexpr int t16_ctl_floats(int pslots, int slots) { return t16_ctl_base(slots) + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
 // what the LDS beside the tables and 16 wave regions leaves: partials 32 signals deep and 64 statistics slots where they fit
+// own planes per wave: two where the LDS has room for them (the second one holds the previous step's image: "Two planes" below)
 template <int KLO, int KC>
-constexpr int t16_room() { return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(); }
+constexpr int t16_planes()
+{
+    return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(2) >= t16_ctl_floats(16, kT16MaxSlots / 2) ? 2 : 1;
+}
+template <int KLO, int KC>
+constexpr int t16_room() { return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(t16_planes<KLO, KC>()); }
 template <int KLO, int KC>
 constexpr int t16_slots() { return t16_room<KLO, KC>() >= t16_ctl_floats(16, kT16MaxSlots) ? kT16MaxSlots : kT16MaxSlots / 2; }
 template <int KLO, int KC>
@@ -170,10 +176,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     static_assert(PSLOTS >= 16, "the CU's own partials need LDS beside the wave regions");
     float* part_lds = smem + ATAB + t16_ctl_base(MS);                        // [PSLOTS][kT16MaxCpc][6]
     int* pcnt_lds = reinterpret_cast<int*>(part_lds + PSLOTS * kT16MaxCpc * kT16PartFloats);   // [PSLOTS][2] partials delivered per block
-    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS, MS) + wv * C::wave_floats();
+    constexpr int PLANES = t16_planes<KLO, KC>();
+    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS, MS) + wv * C::wave_floats(PLANES);
     u2* xrec = reinterpret_cast<u2*>(wbase);
-    f2* own_base = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
-    int* flag = reinterpret_cast<int*>(own_base + 16 * C::LD);
+    f2* own_first = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
+    int* flag = reinterpret_cast<int*>(own_first + PLANES * 16 * C::LD);
     int* tq = flag + kCanonFlagWords;
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
@@ -360,6 +367,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned t0 = static_cast<unsigned>(wall_clock64());
+#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE == 3      // development: the resolver resolves, nobody else waits (results invalid)
+        if (try_claim(ko)) resolve_owned(ko, t0, lane_r);
+        return;
+#endif
         for (unsigned spins = 0;; ++spins) {
             if ((spins & 15u) == 0u && try_claim(ko)) { resolve_owned(ko, t0, lane_r); return; }
             if ((spins & 31u) == 31u && expired(t0)) { gave_up(); leave(); }
@@ -438,6 +449,15 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
     int slot = 0;                                        // the slot this step fills (steps take the slots in turn)
+    // Two planes (where the LDS has them: the displaced plane's 47 kB, fsst_canon128.hpp "One plane").  The steps write the planes in
+    // turn, and a step's image stays in its plane for a whole step: it moves into the registers at the END OF THE NEXT step, when the
+    // other plane holds that step's image.  A group's statistics are therefore wanted THREE steps after its partial was published
+    // instead of two -- a third held group at no instruction and no register (a third image in registers spilled, parked in global
+    // memory it cost 6 %: profiles/r05_team_diet.txt) --, which is what the waits for statistics, 4-5 % of the kernel, were short of.
+    int cur = 0;                                         // the plane this step transforms into
+    bool p_valid = false;                                // the OTHER plane holds the previous step's image: group (p_ko, p_g), scale p_inv
+    int p_ko = 0, p_g = 0;
+    float p_inv = 0.0f;
     draw(-1);
     if (saw_dead) return;
     if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
@@ -459,6 +479,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
+        f2* own_base = own_first + cur * (16 * C::LD);
         canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
                                            [&]() -> const float* { return P()->x + static_cast<unsigned long long>(b) * static_cast<unsigned>(P()->xstride); }, n, tg, P()->atab + kCanonAtabFloats);
         const float inv_cur = tile.inv;
@@ -556,7 +577,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         // per float4 of the image its offsets, then its cells -- it was eleven, one behind the other, a tenth of the wave's time per group):
         // first the words that only depend on the lane and the slot -- is the leaving group's signal resolved, which statistics entry and
         // which cells each of the lane's three float4 takes --, then, behind one wait, the statistics entries and the new image's cells.
-        {
+        // (with two planes the image that moves in is the PREVIOUS step's, from the other plane)
+        auto move_in = [&](const f2* src_plane, float inv_src, int ko_src, int g_src) {
             int ko_o = 0, g_o = 0;
             static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) { ko_o = ko_hs[decltype(S)::value]; g_o = g_hs[decltype(S)::value]; } });
             const bool full = nheld == DEPTH;
@@ -571,7 +593,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
 #endif
             } else ++nheld;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(own_base)));
+            unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(src_plane)));
             asm volatile("" : "+s"(obase));
             auto cell = [&](unsigned off) -> f2 {
                 const lds_float* q = (const lds_float*)static_cast<size_t>(obase + off);
@@ -579,7 +601,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             };
             const f2 lo0 = cell(pk0 & 0xffffu), hi0 = cell(pk0 >> 16), lo1 = cell(pk1 & 0xffffu), hi1 = cell(pk1 >> 16),
                      lo2 = cell(pk2 & 0xffffu), hi2 = cell(pk2 >> 16);
-            const f2 sc = {inv_cur, inv_cur};
+            const f2 sc = {inv_src, inv_src};
             static_for<DEPTH>([&](auto S) {
                 constexpr int sl = decltype(S)::value;
                 if (slot == sl) {
@@ -618,12 +640,49 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                     held_put<6 * sl + 0>(lo0, sc); held_put<6 * sl + 1>(hi0, sc);
                     held_put<6 * sl + 2>(lo1, sc); held_put<6 * sl + 3>(hi1, sc);
                     held_put<6 * sl + 4>(lo2, sc); held_put<6 * sl + 5>(hi2, sc);
-                    ko_hs[sl] = ko_cur; g_hs[sl] = g_cur;
+                    ko_hs[sl] = ko_src; g_hs[sl] = g_src;
                 }
             });
-        }
-        slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
+            slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
+        };
+        if constexpr (PLANES == 2) {
+            if (p_valid) move_in(own_first + (cur ^ 1) * (16 * C::LD), p_inv, p_ko, p_g);
+            p_valid = true; p_inv = inv_cur; p_ko = ko_cur; p_g = g_cur;
+            cur ^= 1;
+        } else
+            move_in(own_base, inv_cur, ko_cur, g_cur);
         wave_sync();
+    }
+    // ---- the list is done: the image that still sits in its plane moves in (the oldest held group leaves for it) ...
+    if constexpr (PLANES == 2) {
+        if (p_valid) {
+            int ko_o = 0, g_o = 0;
+            static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) { ko_o = ko_hs[decltype(S)::value]; g_o = g_hs[decltype(S)::value]; } });
+            (void)g_o;
+            const f2* src_plane = own_first + (cur ^ 1) * (16 * C::LD);
+            const bool full = nheld == DEPTH;
+            if (full) signal_statistics(ko_o); else ++nheld;
+            static_for<DEPTH>([&](auto S) {
+                constexpr int sl = decltype(S)::value;
+                if (slot == sl) {
+                    if (full) emit_held(S, ko_hs[sl], g_hs[sl]);
+                    int lane_r = lane;
+                    asm volatile("" : "+v"(lane_r));
+                    unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(src_plane)));
+                    const f2 sc = {p_inv, p_inv};
+                    static_for<3>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        const unsigned pk = ppk_lds[i * 64 + lane_r];
+                        const lds_float* q0 = (const lds_float*)static_cast<size_t>(obase + (pk & 0xffffu));
+                        const lds_float* q1 = (const lds_float*)static_cast<size_t>(obase + (pk >> 16));
+                        held_put<6 * sl + 2 * i>(f2{q0[0], q0[2]}, sc);
+                        held_put<6 * sl + 2 * i + 1>(f2{q1[0], q1[2]}, sc);
+                    });
+                    ko_hs[sl] = p_ko; g_hs[sl] = p_g;
+                }
+            });
+            slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
+        }
     }
     // ---- the list is done: the held groups leave, oldest first
     for (int i = 0; i < nheld; ++i) {

@@ -545,7 +545,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
     constexpr int PSLOTS = t16_pslots<KLO, KC>();        // signals whose partials a CU keeps in LDS at a time
     constexpr int MS = t16_slots<KLO, KC>();             // statistics / mailbox slots the kernel's LDS has room for
-    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS, MS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats()) * sizeof(float);
+    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS, MS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats(t16_planes<KLO, KC>())) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     if (lds < 84 * 1024) lds = 84 * 1024;
     auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
@@ -576,7 +576,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (cp.xstride < 1 || cp.xstride > 0x7fffffffLL || batch > 0x7fffffffLL) return 0;      // (the kernel's 32-bit signal index and stride)
     // slots: a CU runs at most held_pos list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
     // 2 lead + 2 signals later at the earliest (fsst_team16.hpp "Progress")
-    const int held_pos = WPB * (DEPTH + 3);                  // list positions a CU's waves hold: DEPTH held + transformed + landed + drawn each
+    const int held_pos = WPB * (DEPTH + 2 + t16_planes<KLO, KC>());   // list positions a CU's waves hold: DEPTH held (+ one in its plane) + transformed + landed + drawn each
     const int lead = (held_pos + G / T - 1) / (G / T) + 1;
     int slots = 8;
     while (slots < 2 * lead + 2) slots *= 2;
