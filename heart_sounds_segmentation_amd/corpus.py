@@ -115,8 +115,9 @@ class CorpusBuilder:
         nfr_np = np.where(L_np <= 0, 1, L_np).astype(np.int64)
         nfr = [int(v) for v in nfr_np]
         total = int(nfr_np.sum())
-        have_labels = total > 0 and len(kept_all) > 0 and all(kept_all)      # (the same answer on every rank, also on one without frames)
-        have_labels = have_labels and len(recs) > 0
+        # (decided on the WHOLE list, before the cut: the same answer on every rank -- a rank whose shard holds no frames returns an
+        #  empty (0, frame_len) int64 tensor, not None, when the corpus is labelled, so that a gather of the labels finds every rank in it)
+        have_labels = len(kept_all) > 0 and all(kept_all)
         # groups of about `windows_per_launch` frames (a launch per recording -- 33 frames -- leaves the chip idle)
         groups: List[Tuple[int, int]] = []
         g0, acc = 0, 0

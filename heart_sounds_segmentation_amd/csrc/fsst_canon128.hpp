@@ -251,10 +251,13 @@ __device__ __forceinline__ bool canon_put(f2* row0, int kpi, int row, f2 V)
 // the group's first output column, for the float64 tie path.
 // (xsig: the signal's samples for the float64 rounding-tie path -- a pointer, or a callable that makes it: a kernel whose signal base is
 //  a 64-bit product per group hands over the recipe and pays for it in the rare path only)
-template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*>
+// (mid: a callable run once between the fold and the spectra -- fsst_team16_kernel asks for the statistics of the group that leaves at
+//  the end of the step from there: late enough to find them, early enough for the answer to be back when the transform is done)
+struct CanonNoMid { __device__ __forceinline__ void operator()() const {} };
+template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*, class Mid = CanonNoMid>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
-                                            XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
+                                            XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr, Mid mid = Mid{})
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
@@ -274,6 +277,10 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u2*)(xrec + j + 16 * g)));
     unsigned aaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u4*)(reinterpret_cast<const u4*>(atab) + lane_o)));
     asm volatile("" : "+v"(xaddr), "+v"(aaddr));
+#ifdef HSS_ABL_B128
+    unsigned xaddr2 = (xaddr & ~15u) + static_cast<unsigned>(j + 16 * g) * 8u;      // (16 bytes per lane, contiguous, aligned)
+    asm volatile("" : "+v"(xaddr2));
+#endif
     const lds_u4* ab = (const lds_u4*)static_cast<size_t>(aaddr);
     int pair = g;
     asm volatile("" : "+v"(pair));
@@ -293,7 +300,11 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
             constexpr int n = g0 + decltype(I)::value;
             // records f + n + 16 kk and + 64 in ONE instruction and one register quad (left to itself the compiler pairs
             // record n with n + 1 -- adjacent addresses -- and then shuffles six registers per two taps)
+#ifdef HSS_ABL_B128      // development: what ONE 16-byte read per tap would cost (wrong operands: results invalid)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[n - g0]) : "v"(xaddr2), "n"(16 * n) : "memory");
+#else
             asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(b[n - g0]) : "v"(xaddr), "n"(n), "n"(n + 64) : "memory");
+#endif
             a[n - g0] = ab[n * 64];
         });
         // (the compiler does not count LDS operations issued from inline assembly: wait for them here; its own counts for
@@ -311,9 +322,18 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         __builtin_amdgcn_sched_barrier(0);
     });
     CPROBE(0);
+#if !defined(HSS_T16_PF_AT) || HSS_T16_PF_AT == 1
+    mid();
+#endif
 #if !defined(HSS_CANON_ABLATE) || HSS_CANON_ABLATE < 5
     fft_n<NT>(za);
+#if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 2
+    mid();
+#endif
     fft_n<NT>(zb);
+#endif
+#if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 3
+    mid();
 #endif
     CPROBE(1);
     // ("Offsets" above) a tile staged without its mean: + mean x the spectrum of the all-ones frame, ONE block between the spectra and
@@ -377,6 +397,15 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
                     });
                 }
             }
+            // (this block's loads and register RELOADS are back before the paths merge -- the allocator spills the spectra around this block
+            //  and reloads them at its very end; left pending, they make the wait-count pass put an s_waitcnt vmcnt(0) behind the merge:
+            //  on the plain path too, in the middle of every transform, where it waits for whatever the caller has in flight -- the next
+            //  tile's samples, the previous group's stores.  The empty statements make the reloads happen in front of the wait.)
+            asm volatile("" : "+v"(za[0]), "+v"(za[1]), "+v"(za[2]), "+v"(za[3]), "+v"(za[4]), "+v"(za[5]), "+v"(za[6]), "+v"(za[7]),
+                              "+v"(za[8]), "+v"(za[9]), "+v"(za[10]), "+v"(za[11]), "+v"(za[12]), "+v"(za[13]), "+v"(za[14]), "+v"(za[15]));
+            asm volatile("" : "+v"(zb[0]), "+v"(zb[1]), "+v"(zb[2]), "+v"(zb[3]), "+v"(zb[4]), "+v"(zb[5]), "+v"(zb[6]), "+v"(zb[7]),
+                              "+v"(zb[8]), "+v"(zb[9]), "+v"(zb[10]), "+v"(zb[11]), "+v"(zb[12]), "+v"(zb[13]), "+v"(zb[14]), "+v"(zb[15]));
+            HSS_RARE_VMEM_DONE();
         }
     }
 

@@ -544,8 +544,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
     // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
     constexpr int PSLOTS = t16_pslots<KLO, KC>();        // signals whose partials a CU keeps in LDS at a time
-    constexpr int MS = t16_slots<KLO, KC>();             // statistics / mailbox slots the kernel's LDS has room for
-    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS, MS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats(t16_planes<KLO, KC>())) * sizeof(float);
+    constexpr int MS = kT16MaxSlots;                     // mailbox slots per team (global memory)
+    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS) + static_cast<size_t>(WPB) * t16_wave_floats<KLO, KC>(t16_planes<KLO, KC>())) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     if (lds < 84 * 1024) lds = 84 * 1024;
     auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
@@ -584,7 +584,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (lead + 1 > PSLOTS) return 0;                     // (very short signals: more signals in flight per CU than its LDS keeps partials for)
     int rc;
     if ((rc = ensure_status(pl)) != 0) return rc;
-    const size_t words = static_cast<size_t>(nteams) * slots * kT16MaxBlocks * kT16BlockWords;
+    const size_t words = static_cast<size_t>(nteams) * slots * kT16SlotWords;
     if (words > pl->mail_cap) {
         if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
         HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
@@ -911,6 +911,26 @@ int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nw
 #endif
 
 int hssfsst_version(void) { return HSSFSST_VERSION; }
+#ifdef HSS_T16_TLPROBE       // development only (tools/timeline.py)
+int hssfsst_dev_t16_tl(unsigned* out, int clear)
+{
+    constexpr size_t N = 16 * 16 * hssfsst::kTlCap * 2;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_tl), sizeof(unsigned) * N) != hipSuccess) return -2;
+    if (clear) { static unsigned z[N]; if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_tl), z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE)      // development only (tools/xcc_speed.py): out[256 * 4 + 8]
+int hssfsst_dev_t16_xcc(unsigned long long* out, int clear)
+{
+    constexpr size_t N = 256 * 4 + 8;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_xcc), sizeof(unsigned long long) * N) != hipSuccess) return -2;
+    if (clear) { static unsigned long long z[N]; if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_xcc), z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 const char* hssfsst_last_error(void) { return g_err; }
 
 int hssfsst_device_count(void)

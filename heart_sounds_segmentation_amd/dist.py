@@ -65,7 +65,9 @@ def all_gather_blocks(local: torch.Tensor, total: int, group: Optional[dist.Proc
                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-gather per-rank feature blocks (block split of ``total`` by ``shard_bounds``) into the
     full batch, in rank order.  Equal blocks: a single ``all_gather_into_tensor`` straight into the
-    result; ragged: one all_gather over per-rank views of the result."""
+    result; ragged: ONE ``all_gather_into_tensor`` of blocks padded to the largest count + a compaction
+    of the other ranks' rows (``_gather_counts``; the single uneven collective is opt-in,
+    ``HSSFSST_DIST_UNEVEN=1``).  Never run under RCCL with more than one rank (no multi-GPU node)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [h - l for l, h in (shard_bounds(total, world, r) for r in range(world))]
     if local.shape[0] != counts[rank]:
@@ -129,31 +131,39 @@ def _gather_counts(local: torch.Tensor, counts: Sequence[int], tail: Tuple[int, 
     for c in counts:
         offs.append(offs[-1] + c)
     mine = out[offs[rank]: offs[rank + 1]]
-    if local.data_ptr() != mine.data_ptr() or local.device != dev:     # (a block computed in place in `out` needs no copy)
-        mine.copy_(local, non_blocking=True)
+    in_place = local.data_ptr() == mine.data_ptr() and local.device == dev      # (a block computed in place in `out` needs no copy)
+    nccl = dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower()
     if len(set(counts)) == 1:
+        if not in_place:
+            mine.copy_(local, non_blocking=True)
         # (RCCL gathers in place when the send buffer is the rank's own slot of the receive buffer; gloo gets a copy)
-        dist.all_gather_into_tensor(out, mine if dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() else mine.clone(),
-                                    group=group)
+        dist.all_gather_into_tensor(out, mine if nccl else mine.clone(), group=group)
         return out
-    if (dev.type == "cuda" and "nccl" in str(dist.get_backend(group)).lower() and min(counts) > 0
-            and os.environ.get("HSSFSST_DIST_UNEVEN", "0") == "1"):
+    if nccl and min(counts) > 0 and os.environ.get("HSSFSST_DIST_UNEVEN", "0") == "1":
         # OPT-IN (HSSFSST_DIST_UNEVEN=1): one dist.all_gather over per-rank views of the result.  torch lowers unequal blocks under
         # NCCL / RCCL to a coalesced group of per-rank broadcasts (ProcessGroupNCCL::allgather, as recalled -- not checked against this
-        # build); it has NEVER run here with more than one rank (no multi-GPU node in rounds 1-5), and whether RCCL takes empty blocks is
+        # build); it has NEVER run here with more than one rank (no multi-GPU node in rounds 1-6), and whether RCCL takes empty blocks is
         # unknown, so blocks without rows never come this way.  The default below uses only all_gather_into_tensor of equal blocks --
         # the collective every N-rank RCCL job exercises -- at the price of a padded staging buffer and one compaction pass.
+        if not in_place:
+            mine.copy_(local, non_blocking=True)
         views = [out[offs[r]: offs[r + 1]] for r in range(world)]
         dist.all_gather(views, mine, group=group)
         return out
     # ragged blocks (RCCL by default, gloo always -- gloo insists on equal blocks): ONE all_gather_into_tensor of blocks padded to the
-    # largest count, then the valid rows of every block into place; a rank without rows takes part with a block of padding
+    # largest count, then the valid rows of the OTHER ranks' blocks into place; a rank without rows takes part with a block of padding.
+    # Nothing is zero-filled that is overwritten anyway: the staging buffer is uninitialised memory, only the padding rows of this
+    # rank's send block are cleared (they travel), and the rank's own block goes local -> pad -> (its slot of `out` straight from local).
     cmax = max(counts)
-    stage = torch.zeros((world, cmax) + tuple(tail), dtype=local.dtype, device=dev)
-    pad = torch.zeros((cmax,) + tuple(tail), dtype=local.dtype, device=dev)
-    pad[: counts[rank]].copy_(mine)
+    stage = torch.empty((world, cmax) + tuple(tail), dtype=local.dtype, device=dev)
+    pad = torch.empty((cmax,) + tuple(tail), dtype=local.dtype, device=dev)
+    pad[: counts[rank]].copy_(local, non_blocking=True)
+    if counts[rank] < cmax:
+        pad[counts[rank]:].zero_()
+    if not in_place:
+        mine.copy_(local, non_blocking=True)
     dist.all_gather_into_tensor(stage.view((world * cmax,) + tuple(tail)), pad, group=group)
     for r in range(world):
-        if counts[r]:
+        if counts[r] and r != rank:
             out[offs[r]: offs[r + 1]].copy_(stage[r, : counts[r]])
     return out

@@ -38,6 +38,8 @@ def main():
         xh = np.tile(np.cos(2 * np.pi * (16 * fs / nwin) * np.arange(2000) / fs).astype(np.float32), (B, 1))
     elif kind == "noise":
         xh = synth.noise_windows(B, 2000)
+    elif kind == "zeros":
+        xh = np.zeros((B, 2000), dtype=np.float32)
     else:
         xh = synth.pcg_windows(B, 2000)
     X = torch.from_numpy(xh).cuda()
