@@ -447,6 +447,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (lane_r < 3) {
                 const unsigned x = lane_r == 2 ? b.x : a.x, y = lane_r == 2 ? b.z : a.z, z = lane_r == 0 ? a.x : b.x, w = lane_r == 0 ? a.z : b.z;
                 wstat[lane_r] = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE == 4       // development: nobody waits, the z-score runs on PLAUSIBLE statistics (the stored data look like features)
+                if (!ok) wstat[lane_r] = make_float4(0.01f, 3.0f, -0.02f, 2.5f);
+#endif
             }
         } else {
             TL(5u, ko, 0);
