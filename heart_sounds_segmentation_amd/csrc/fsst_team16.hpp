@@ -67,11 +67,14 @@
 namespace hssfsst {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
+__device__ unsigned g_t16_blk[256 * 16 * 8];             // per wave of the LAST launch: misses, looks, ticks waited, finisher ticks, signals finished
+#endif
 #ifdef HSS_T16_TLPROBE       // development (tools/timeline.py): team 0's waves log {event << 28 | signal << 8 | group, time} of the LAST launch
 constexpr int kTlCap = 512;
 __device__ unsigned g_t16_tl[16 * 16 * kTlCap * 2];
 #endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE)      // development (tools/xcc_speed.py): per block {XCC_ID, start, end (100 MHz ticks), identity} of the LAST launch
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE) || defined(HSS_T16_BLKPROBE)      // development (tools/xcc_speed.py): per block {XCC_ID, start, end (100 MHz ticks), identity} of the LAST launch
 __device__ unsigned long long g_t16_xcc[256 * 4 + 8];      // [1024] statistics not there in time, [1025] further looks
 #endif
 
@@ -88,7 +91,7 @@ constexpr int kT16WaveStat = 12;             // per wave, behind its canonical r
 constexpr int kT16StageWords = 8;            // per wave, in the block's control words: the 32-byte copy of a signal's four tagged statistics words
                                              // (BELOW 64 KiB: the LDS target of global_load_lds is M0's sixteen bits)
 // [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets | the waves' fetched statistics words
-constexpr int t16_ctl_base() { return 16 + 64 + 192 + 16 * kT16StageWords; }
+constexpr int t16_ctl_base() { return 16 + 64 + 192 + 2 * 16 * kT16StageWords; }
 // ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
 constexpr int t16_ctl_floats(int pslots) { return t16_ctl_base() + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
 // own planes per wave: two where the LDS has room for them (the second one holds the previous step's image: "Two planes" below)
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     int* tq = flag + kCanonFlagWords;
     unsigned* stage = reinterpret_cast<unsigned*>(smem + ATAB + 272) + wv * kT16StageWords;   // [8] the fetched statistics words {value, tag} x 4 (16-byte aligned)
     float4* wstat = reinterpret_cast<float4*>(tq + kCanonTieWords);          // [3] this wave's z-score table of the group that leaves
-    static_assert(WPB <= 16 && (ATAB + 272 + 16 * kT16StageWords) * 4 < 65536, "global_load_lds targets sit in the first 64 KiB");
+    unsigned* stage2 = stage + 16 * kT16StageWords;                          // [8] the second look: asked for behind the transform
+    static_assert(WPB <= 16 && (ATAB + 272 + 2 * 16 * kT16StageWords) * 4 < 65536, "global_load_lds targets sit in the first 64 KiB");
     static_assert((2 * kCanonRecs + PLANES * 2 * 16 * C::LD + kCanonFlagWords + kCanonTieWords) % 4 == 0 && t16_wave_floats<KLO, KC>(PLANES) % 4 == 0 &&
                   (ATAB + t16_ctl_floats(PSLOTS)) % 4 == 0, "the statistics words are the target of a 16-byte copy");
 
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
-    if (lane < 8) stage[lane] = 0u;                                          // (no tag is 0)
+    if (lane < 8) { stage[lane] = 0u; stage2[lane] = 0u; }                   // (no tag is 0)
     if (threadIdx.x < 2 * PSLOTS) pcnt_lds[threadIdx.x] = 0;
     // Block identity = ARRIVAL number ("Giving up" above)
     if (threadIdx.x == 64)
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     };
     auto draw = [&](int after_ko) { draw_ask(after_ko); draw_take(); };
 
-#ifdef HSS_T16_XCCPROBE
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
     unsigned pb_miss = 0u, pb_looks = 0u, pb_blocked = 0u, pb_fin = 0u, pb_nfin = 0u;
 #endif
 #ifdef HSS_T16_MISSPROBE     // development: how many groups leave without their statistics being there (one counter, one atomic per wave)
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (is_dead()) leave();
             __builtin_amdgcn_s_sleep(4);
         }
-#ifdef HSS_T16_XCCPROBE
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
         pb_fin += static_cast<unsigned>(wall_clock64()) - t0; ++pb_nfin;
 #endif
         // stats_from_blocks(): lane (blk % 16, q) adds its blocks blk, blk + 16 in that order, then stats_finish
@@ -419,16 +423,16 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     //  operation it cannot tell apart from the copy's target -- the transform's first store into the plane, a hundred instructions on:
     //  the whole trip to the mailbox waited for in every group, +20 % on the kernel.  Nothing reads `stage` before the explicit wait.)
     const unsigned stage_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned*)stage))));
-    auto stats_prefetch = [&](int ko) {
+    auto stats_prefetch = [&](int ko, unsigned target_lds) {
         const gu64* f = mail + static_cast<size_t>(ko & smask) * nwords + kT16MaxBlocks * kT16BlockWords;
         if (lane < 2) {
             const gu64* fl = f + 2 * lane;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(fl), "s"(stage_lds) : "m0", "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(fl), "s"(target_lds) : "m0", "memory");
         }
     };
     // The statistics of signal ko into this wave's z-score table: from the words the wave asked for in time (the rule), else by
     // looking at the mailbox until they are there -- every wait bounded; a wave that finds the launch given up does not come back.
-    auto stats_take = [&](int ko) __attribute__((always_inline)) {
+    auto stats_take = [&](int ko, bool look2 = false) __attribute__((always_inline)) {
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         } else {
             TL(5u, ko, 0);
             // not there in time: the team's finisher is still at it, or its words are still on their way
-#ifdef HSS_T16_XCCPROBE
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
             ++pb_miss;
             const unsigned tb0 = static_cast<unsigned>(wall_clock64());
 #endif
@@ -469,11 +473,25 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 wstat[2] = make_float4(r.z, r.w, r.z, r.w);
             }
 #else
-            // looks at the signal's four words until they are there (four lanes, eight bytes each: a light look)
+            // the second look (asked for behind the transform) first, then looks at the signal's four words until they are there (four lanes,
+            // eight bytes each: a light look)
             const unsigned t0 = static_cast<unsigned>(wall_clock64());
             const gu64* f = mail + static_cast<size_t>(ko & smask) * nwords + kT16MaxBlocks * kT16BlockWords;
             u4 a2, b2;
-            for (unsigned tries = 0;; ++tries) {
+            bool have2 = false;
+#ifndef HSS_T16_NO_LOOK2
+            if (look2) {
+                if (d_valid) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const u4* s24 = reinterpret_cast<const u4*>(stage2);
+                a2 = s24[0]; b2 = s24[1];
+                have2 = a2.y == tag && a2.w == tag && b2.y == tag && b2.w == tag;
+                have2 = __builtin_amdgcn_readfirstlane(have2 ? 1 : 0) != 0;
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
+                if (have2) ++pb_looks;
+#endif
+            }
+#endif
+            for (unsigned tries = 0; !have2; ++tries) {
                 if (lane_r < 4) {
                     const unsigned long long w = __hip_atomic_load(f + lane_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     reinterpret_cast<unsigned long long*>(stage)[lane_r] = w;
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 wstat[lane_r] = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
             }
 #endif
-#ifdef HSS_T16_XCCPROBE
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
             pb_blocked += static_cast<unsigned>(wall_clock64()) - tb0;
 #endif
         }
@@ -607,7 +625,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         int pf_ko = -1;
         if (nheld == DEPTH && (PLANES == 1 || p_valid))
             static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) pf_ko = ko_hs[decltype(S)::value]; });
-        auto mid = [&]() { if (pf_ko >= 0) stats_prefetch(pf_ko); };
+        auto mid = [&]() { if (pf_ko >= 0) stats_prefetch(pf_ko, stage_lds); };
 #if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 0
         mid();
 #endif
@@ -622,6 +640,12 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         // stores were issued: its wait-count pass merges what may be pending over every path through the loop, and a register reload
         // inside the transform's rare paths made it protect the fold's registers at the head of the loop (HSS_RARE_VMEM_DONE, fsst_canon128.hpp).
         HSS_RARE_VMEM_DONE();
+#ifndef HSS_T16_NO_LOOK2
+        // a second look, asked for here and looked at only if the first one came too early: most waves that are early are early by less than
+        // the trip this look has already made when the group leaves (stats_take waits for it with a counted s_waitcnt: the next tile's three
+        // sample loads are younger)
+        if (pf_ko >= 0) stats_prefetch(pf_ko, stage_lds + 16u * kT16StageWords * 4u);
+#endif
         if (d_valid) land();
         // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
         //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
@@ -742,7 +766,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             asm volatile("" : "+v"(lane_r));
             const unsigned cofs = cls_lds[lane_r];
             const unsigned pk0 = ppk_lds[lane_r], pk1 = ppk_lds[64 + lane_r], pk2 = ppk_lds[128 + lane_r];
-            if (full) stats_take(ko_o); else ++nheld;
+            if (full) stats_take(ko_o, pf_ko == ko_o); else ++nheld;
             unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(src_plane)));
             asm volatile("" : "+s"(obase));
             auto cell = [&](unsigned off) -> f2 {
@@ -855,14 +879,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         __hip_atomic_fetch_add(&g_t16_xcc[1025], static_cast<unsigned long long>(pm_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
-#ifdef HSS_T16_XCCPROBE
-    if (lane == 0) {
-        __hip_atomic_fetch_add(&g_t16_xcc[1024], static_cast<unsigned long long>(pb_miss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&g_t16_xcc[1025], static_cast<unsigned long long>(pb_looks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&g_t16_xcc[1026], static_cast<unsigned long long>(pb_blocked), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&g_t16_xcc[1027], static_cast<unsigned long long>(pb_fin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&g_t16_xcc[1028], static_cast<unsigned long long>(pb_nfin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
+    if (lane == 0 && virt < 256) {      // (one slot per wave: 4096 waves adding to five words took longer than the kernel)
+        unsigned* e = g_t16_blk + (virt * 16 + wv) * 8;
+        e[0] = pb_miss; e[1] = pb_looks; e[2] = pb_blocked; e[3] = pb_fin; e[4] = pb_nfin;
     }
+#endif
+#ifdef HSS_T16_XCCPROBE
     if (lane == 0 && virt < 256) {      // (the last wave of the block to get here leaves the latest end)
         const unsigned long long t1 = wall_clock64();
         g_t16_xcc[4 * virt + 0] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) | (static_cast<unsigned long long>(blockIdx.x) << 8);

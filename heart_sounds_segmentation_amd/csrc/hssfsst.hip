@@ -25,6 +25,7 @@
 #include "fsst_mfma128.hpp"
 #include "fsst_canon128.hpp"
 #include "fsst_team16.hpp"
+#include "fsst_teamq.hpp"
 #ifndef HSS_T16_WPB
 #define HSS_T16_WPB 16
 #define HSS_T16_DEPTH 2
@@ -64,6 +65,7 @@ struct DebugSwitches {
     bool no_canon = false;        // the canonical band on the general kernels (fsst_mfma128.hpp)
     bool no_team = false;         // never the team kernel
     bool team_only = false;       // the team kernel or two launches, never one CU per signal
+    bool team_static = false;     // the team kernel with a fixed share of every signal per CU (fsst_team16_kernel; A/B)
     bool team_force_fallback = false;   // every team launch finds itself given up (tests of the gated fallback)
     bool force_dft = false;       // every window length on the any-length kernel
     bool force_generic = false;   // every radix length on the generic VALU kernel
@@ -85,7 +87,7 @@ const DebugSwitches& debug_switches()
             const int iv = val ? std::atoi(val) : 0;
             const bool on = !val || val[0] == '\0' || iv != 0 || val[0] == 'y' || val[0] == 't';
             if (key == "no_fused") d.no_fused = on; else if (key == "no_canon") d.no_canon = on;
-            else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
+            else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on; else if (key == "team_static") d.team_static = on;
             else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
             else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
             else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "team") d.team = iv;
@@ -241,6 +243,10 @@ struct hssfsst_plan {
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
     unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
+    unsigned* d_tickets = nullptr; size_t tickets_cap = 0;   // fsst_teamq_kernel: [2][teams] ticket counters, used in turn (tick_par)
+    int tick_par = 0;
+    unsigned long long* d_mailq = nullptr; size_t mailq_cap = 0;   // fsst_teamq_kernel: mailboxes [teams][slots][8 G + 8] (8-byte words)
+    unsigned teamq_seq = 0;
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
@@ -621,6 +627,92 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     return 1;
 }
 
+// Team kernel with the work handed out per team (fsst_teamq.hpp): one ticket counter per team, a group's partial straight to the mailbox,
+// one finisher per signal.  Returns 1 when it launched, 0 when this exec should take another path, < 0 on error.
+template <int KLO, int KC, int WPB, int DEPTH>
+int launch_teamq(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
+{
+    using namespace hssfsst;
+    const int G = ngroups;
+    if (G < 1 || G > kFusedMaxGroups) return 0;
+    constexpr int PLANES = tq_planes<KLO, KC>();
+    size_t lds = (kCanonLdsTabFloats + tq_ctl_floats() + static_cast<size_t>(WPB) * tq_wave_floats<KLO, KC>(PLANES)) * sizeof(float);
+    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
+    if (lds < 84 * 1024) lds = 84 * 1024;                // (one block per CU whatever its size: the teams count on it)
+    auto kern = fsst_teamq_kernel<KLO, KC, WPB, DEPTH>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
+    if (pl->team16_cus == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
+        pl->team16_cus = (per_cu >= 1 && cus >= 1) ? cus : -1;
+    }
+    if (pl->team16_cus < 1) return 0;
+    // team size: the smallest power of two whose waves take a signal's groups in about half a round (16 T >= 2 G); HSSFSST_TEAM=n overrides
+    const int team_env = debug_switches().team;
+    int T = 1;
+    while ((WPB / 2) * T < G) T *= 2;
+    if (team_env > 0) { T = 1; while (2 * T <= team_env) T *= 2; }
+    if (T > pl->team16_cus || T > 256) return 0;
+    const int grid = (pl->team16_cus / T) * T;
+    const int nteams = grid / T;
+    if ((batch + nteams - 1) / nteams > 65535) return 0; // (16 bits of the signal ordinal in the mailbox tags)
+    if (cp.xstride < 1 || cp.xstride > 0x7fffffffLL || batch > 0x7fffffffLL) return 0;      // (the kernel's 32-bit signal index and stride)
+    // slots: a team's waves hold at most 6 tickets each (two held groups, one in its plane, transformed, landed, drawn): `lead` signals in
+    // flight; a slot is reused 2 lead + 2 signals later at the earliest
+    const int inflight = T * WPB * 6;
+    const int lead = (inflight + G - 1) / G + 1;
+    int slots = 8;
+    while (slots < 2 * lead + 2) slots *= 2;
+    const int slot_words = kTqGroupWords * G + 8;
+    const size_t words = static_cast<size_t>(nteams) * slots * slot_words;
+    if (slots > 4096 || words * 8 > (static_cast<size_t>(64) << 20)) return 0;
+    int rc;
+    if ((rc = ensure_status(pl)) != 0) return rc;
+    if (words > pl->mailq_cap) {
+        if ((rc = grow(reinterpret_cast<void**>(&pl->d_mailq), &pl->mailq_cap, words, sizeof(unsigned long long))) != 0) return rc;
+        HIP_TRY(hipMemsetAsync(pl->d_mailq, 0, pl->mailq_cap * sizeof(unsigned long long), st));
+        pl->teamq_seq = 0;
+    }
+    if (++pl->teamq_seq > 0xffffu) {                     // tags would repeat: start over from clean mailboxes
+        HIP_TRY(hipMemsetAsync(pl->d_mailq, 0, pl->mailq_cap * sizeof(unsigned long long), st));
+        pl->teamq_seq = 1;
+    }
+    if (nteams > kTqMaxTeams) return 0;
+    if (pl->tickets_cap == 0) {
+        if ((rc = grow(reinterpret_cast<void**>(&pl->d_tickets), &pl->tickets_cap, static_cast<size_t>(2 * kTqMaxTeams) * kTqTicketStride, sizeof(unsigned))) != 0) return rc;
+        HIP_TRY(hipMemsetAsync(pl->d_tickets, 0, pl->tickets_cap * sizeof(unsigned), st));
+        pl->tick_par = 0;
+    }
+    TeamqParams tp{};
+    tp.x = cp.x; tp.out = cp.out; tp.atab = pl->d_atab16; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
+    tp.mail = pl->d_mailq; tp.tickets = pl->d_tickets; tp.r2scale_s = pl->canon_r2s; tp.inv_c = pl->canon_inv_c;
+    tp.n = cp.n; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
+    tp.team = T; tp.slots = slots; tp.slot_words = slot_words; tp.seq = pl->teamq_seq;
+    tp.tick_par = pl->tick_par; pl->tick_par ^= 1;
+    tp.g_magic = static_cast<unsigned>((0x100000000ULL / static_cast<unsigned long long>(G)) + 1ULL);
+    {   // the two float64 divisions of stats_finish (correctly rounded here as there: the same bits)
+        const double total = static_cast<double>(KC) * static_cast<double>(cp.ncols);
+        tp.inv_total = 1.0 / total; tp.inv_total1 = 1.0 / (total - 1.0);
+    }
+    const unsigned spin_us = debug_switches().team_spin_us;
+    tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
+    if ((rc = ensure_team_words(pl, st)) != 0) return rc;
+    if (++pl->team_launch == 0u) pl->team_launch = 1u;
+    tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
+    if (debug_switches().team_force_fallback) {          // tests: every team launch finds itself given up
+        HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
+    }
+    tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
+    pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
+    name_kernel(pl, WPB, grid, "fsst_teamq_kernel<%d, %d, %d, %d> teams of %d", KLO, KC, WPB, DEPTH, T);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, tp);
+    HIP_TRY(hipGetLastError());
+    return 1;
+}
+
 // Canonical-class kernels (fsst_canon128.hpp): nwin = 128, STACK / STACK_UNNORM, the kept band a compile-time constant.  Two bands
 // are instantiated: rows 4..25 = [25, 200] Hz at fs = 1000 (/root/reference/main.py:153-158, the reference's own configuration) and
 // rows 2..25 = [25, 400] Hz at fs = 2000 -- the pass band of the Springer / Schmidt heart-sound segmenters on recordings at
@@ -779,7 +871,10 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
         if (!no_team && canon16) {
-            rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
+            if (debug_switches().team_static)
+                rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
+            else
+                rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_teamq<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
                 // them apart: fsst_team16.hpp "Progress"): the same exec is queued behind it, every kernel of it gated on the
@@ -911,6 +1006,20 @@ int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nw
 #endif
 
 int hssfsst_version(void) { return HSSFSST_VERSION; }
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
+int hssfsst_dev_t16_blk(unsigned* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_blk), sizeof(unsigned) * 256 * 16 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+#ifdef HSS_TQ_BLKPROBE       // development only (tools/blk_probe.py)
+int hssfsst_dev_t16_blk(unsigned* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_tq_blk), sizeof(unsigned) * 256 * 16 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef HSS_T16_TLPROBE       // development only (tools/timeline.py)
 int hssfsst_dev_t16_tl(unsigned* out, int clear)
 {
@@ -921,7 +1030,7 @@ int hssfsst_dev_t16_tl(unsigned* out, int clear)
     return 0;
 }
 #endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE)      // development only (tools/xcc_speed.py): out[256 * 4 + 8]
+#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE) || defined(HSS_T16_BLKPROBE)      // development only (tools/xcc_speed.py): out[256 * 4 + 8]
 int hssfsst_dev_t16_xcc(unsigned long long* out, int clear)
 {
     constexpr size_t N = 256 * 4 + 8;
@@ -1253,6 +1362,8 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
+    if (p->d_mailq) (void)hipFree(p->d_mailq);
+    if (p->d_tickets) (void)hipFree(p->d_tickets);
     if (p->d_arrive) (void)hipFree(p->d_arrive);
     if (p->h_fallback) (void)hipHostFree(const_cast<unsigned*>(p->h_fallback));
     if (p->d_stats) (void)hipFree(p->d_stats);

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Development: how long waves of the team kernel wait for statistics (builds with -DHSS_T16_BLKPROBE: three counters per wave, one atomic each at the end).
+usage: blk_probe.py lib.so [pcg|noise|zeros]"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heart_sounds_segmentation_amd import synth  # noqa: E402
+from tools.canon_check import load  # noqa: E402
+L = load(sys.argv[1]); kind = sys.argv[2] if len(sys.argv) > 2 else "pcg"
+B, n = 1024, 2000
+w = np.ascontiguousarray(synth.kaiser_window(128, 0.5))
+plan = ctypes.c_void_p()
+assert L.hssfsst_plan_create(ctypes.byref(plan), 0, 128, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1000.0, 1, 25.0, 200.0, 2) == 0
+xh = {"pcg": lambda: synth.pcg_windows(B, n), "noise": lambda: synth.noise_windows(B, n), "zeros": lambda: np.zeros((B, n), np.float32)}[kind]()
+X = torch.from_numpy(xh.astype(np.float32)).cuda(); out = torch.empty((B, n, 44), dtype=torch.float32, device="cuda")
+buf = (ctypes.c_uint * (256 * 16 * 8))(); L.hssfsst_dev_t16_blk.argtypes = [ctypes.c_void_p]
+def run(k):
+    for _ in range(k): L.hssfsst_exec(plan, ctypes.c_void_p(X.data_ptr()), B, n, 1, ctypes.c_void_p(out.data_ptr()), 1, None)
+run(300)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for r in range(3):
+    K = 200
+    e0.record(); run(K); e1.record(); e1.synchronize()
+    assert L.hssfsst_dev_t16_blk(buf) == 0
+    a = np.frombuffer(buf, dtype=np.uint32).reshape(4096, 8).astype(np.float64)
+    miss, blocked, fin, nfin = a[:, 0], a[:, 2] / 100.0, a[:, 3] / 100.0, a[:, 4]
+    print(f"{os.path.basename(sys.argv[1])} {kind}: {e0.elapsed_time(e1) / K * 1e3:.1f} us per exec; last launch: misses {miss.sum() / 128000 * 100:.1f} % of the groups, "
+          f"{blocked.sum() / max(miss.sum(), 1):.2f} us waited per miss = {blocked.mean():.2f} us per wave (p90 {np.percentile(blocked, 90):.2f}, max {blocked.max():.2f}); "
+          f"finishers wait {fin.sum() / max(nfin.sum(), 1):.2f} us per signal = {fin.mean():.2f} us per wave; groups per wave min {a[:, 5].min():.0f} max {a[:, 5].max():.0f} sum {a[:, 5].sum():.0f}")

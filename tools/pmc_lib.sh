@@ -13,7 +13,7 @@ out = {}
 for f in sorted(glob.glob("$O/p*/*_results.db")):
     db = sqlite3.connect(f)
     for name, ctr, avg in db.execute("select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
-        if "team16" in name: out[ctr] = avg
+        if "team16" in name or "teamq" in name: out[ctr] = avg
 g = 128000.0
 print("$lib", " ".join(f"{k.replace('SQ_', '')}={v / g:.1f}" for k, v in sorted(out.items())))
 PY
