@@ -85,6 +85,76 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def check_code_object(path: str = None) -> dict:
+    """The SHIPPED code object, looked at: fsst_team16_kernel keeps its held images in v104..v127 through inline assembly and compiles for 104
+    allocatable registers (fsst_team16.hpp) -- a compiler that stopped honouring the limit, started using AGPRs or outlined a call would corrupt
+    features silently.  Disassembles the gfx950 code object inside the library and asserts, for every team kernel: the only instructions
+    that name a register >= v104 are the two accessors, all twelve pairs are used, no AGPR, no call, 128 registers reserved.  Returns counts."""
+    import re
+    import shutil
+    import tempfile
+    path = path or LIB_PATH
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = {t: (shutil.which(t) or os.path.join(llvm, t)) for t in ("clang-offload-bundler", "llvm-objdump", "llvm-readelf")}
+    objcopy = shutil.which("objcopy") or shutil.which("llvm-objcopy") or os.path.join(llvm, "llvm-objcopy")
+    for t in list(tools.values()) + [objcopy]:
+        if not os.path.exists(t):
+            raise RuntimeError(f"check_code_object: {t} not found")
+    with tempfile.TemporaryDirectory() as td:
+        fat, obj = os.path.join(td, "fat.bin"), os.path.join(td, "code.o")
+        subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", path, fat], check=True, capture_output=True)
+        subprocess.run([tools["clang-offload-bundler"], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--output={obj}"], check=True, capture_output=True)
+        dis = subprocess.run([tools["llvm-objdump"], "-d", "--mcpu=gfx950", obj], check=True, capture_output=True, text=True).stdout.split("\n")
+        notes = subprocess.run([tools["llvm-readelf"], "--notes", obj], check=True, capture_output=True, text=True).stdout
+    starts = [i for i, ln in enumerate(dis) if re.match(r"^[0-9a-f]+ <_ZN7hssfsst18fsst_team16_kernel.*>:", ln)]
+    if len(starts) < 2:
+        raise RuntimeError("check_code_object: the team kernels are not in the code object")
+    put = re.compile(r"^\s*v_pk_mul_f32 v\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\]\s*$")
+    get = re.compile(r"^\s*v_pk_add_f32 v\[\d+:\d+\], v\[(\d+):(\d+)\], v\[\d+:\d+\] op_sel")
+    out = {"kernels": 0, "accessor_instructions": 0}
+    for st in starts:
+        seen = set()
+        for ln in dis[st + 1:]:
+            if re.match(r"^[0-9a-f]+ <.*>:", ln):
+                if "_ZN7hssfsst" in ln and "fsst_team16_kernel" not in ln:
+                    break
+                continue
+            code = ln.split("//")[0]
+            if re.search(r"\bs_swappc_b64\b|\bs_call_b64\b|\bs_setpc_b64\b", code):
+                raise RuntimeError(f"check_code_object: a call inside the team kernel: {code.strip()}")
+            if re.search(r"\ba\d+\b|\ba\[\d+:\d+\]|v_accvgpr", code):
+                raise RuntimeError(f"check_code_object: an AGPR inside the team kernel: {code.strip()}")
+            regs = [int(a) for a in re.findall(r"\bv(\d+)\b", code)] + [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
+            if not regs or max(regs) < 104:
+                continue
+            m = put.match(code) or get.match(code)
+            if not (m and int(m.group(1)) >= 104 and int(m.group(2)) == int(m.group(1)) + 1):
+                raise RuntimeError(f"check_code_object: register >= v104 outside the accessors: {code.strip()}")
+            if sum(1 for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", code) if int(b) >= 104) != 1:
+                raise RuntimeError(f"check_code_object: two held pairs in one instruction: {code.strip()}")
+            seen.add(int(m.group(1)))
+            out["accessor_instructions"] += 1
+        if seen != set(range(104, 128, 2)):
+            raise RuntimeError(f"check_code_object: held pairs used: {sorted(seen)}")
+        out["kernels"] += 1
+    # the kernels' metadata: 128 vector registers, no AGPR
+    for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+        if "fsst_team16_kernel" not in blk.split(".symbol:")[0] + blk:
+            continue
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name or "fsst_team16_kernel" not in name.group(1):
+            continue
+        agpr = int(blk.strip().split()[0])
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+        if agpr != 0 or not vg or int(vg.group(1)) != 128:
+            raise RuntimeError(f"check_code_object: {name.group(1)}: agpr_count {agpr}, vgpr_count {vg.group(1) if vg else None}")
+        out["metadata_checked"] = out.get("metadata_checked", 0) + 1
+    if out.get("metadata_checked", 0) < 2:
+        raise RuntimeError("check_code_object: the team kernels' metadata was not found")
+    return out
+
+
 def lib():
     """The loaded C-ABI library; raises RuntimeError when it is absent (no fallback)."""
     global _lib
@@ -115,6 +185,10 @@ def lib():
         L.hssfsst_exec_cols.restype = c_int
         L.hssfsst_exec_frames.argtypes = [vp, vp, c_i64, c_int, c_i64, c_int, c_int, c_int, vp, c_int, vp]
         L.hssfsst_exec_frames.restype = c_int
+        L.hssfsst_exec_pinned.argtypes = [vp, vp, c_int, ctypes.POINTER(vp)]
+        L.hssfsst_exec_pinned.restype = c_int
+        L.hssfsst_pinned_release.argtypes = [vp, vp]
+        L.hssfsst_pinned_release.restype = c_int
         L.hssfsst_normalize_running.argtypes = [vp, vp, c_i64, c_int, vp, vp]
         L.hssfsst_normalize_running.restype = c_int
         L.hssfsst_exec_list.argtypes = [vp, vp, c_i64, vp, c_int, c_i64, c_int, c_int, vp, c_int, vp]

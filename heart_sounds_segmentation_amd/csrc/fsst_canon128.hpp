@@ -251,13 +251,10 @@ __device__ __forceinline__ bool canon_put(f2* row0, int kpi, int row, f2 V)
 // the group's first output column, for the float64 tie path.
 // (xsig: the signal's samples for the float64 rounding-tie path -- a pointer, or a callable that makes it: a kernel whose signal base is
 //  a 64-bit product per group hands over the recipe and pays for it in the rare path only)
-// (mid: a callable run once between the fold and the spectra -- fsst_team16_kernel asks for the statistics of the group that leaves at
-//  the end of the step from there: late enough to find them, early enough for the answer to be back when the transform is done)
-struct CanonNoMid { __device__ __forceinline__ void operator()() const {} };
-template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*, class Mid = CanonNoMid>
+template <int KLO, int KC, int TAPB = 4, bool OFFS = true, class XSig = const float*>
 __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f2* own_base, int* flag, int* tq,
                                             const double* wtab, const double* twtab, const CanonTile& tile, f2 tiny, int lane_o,
-                                            XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr, Mid mid = Mid{})
+                                            XSig xsig, int n, int tg, const float* zc, unsigned long long* cp = nullptr)
 {
     using C = CanonCfg<KLO, KC>;
     constexpr int NT = 16, RQ = 8, NWIN = 128;
@@ -277,10 +274,6 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
     unsigned xaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u2*)(xrec + j + 16 * g)));
     unsigned aaddr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_u4*)(reinterpret_cast<const u4*>(atab) + lane_o)));
     asm volatile("" : "+v"(xaddr), "+v"(aaddr));
-#ifdef HSS_ABL_B128
-    unsigned xaddr2 = (xaddr & ~15u) + static_cast<unsigned>(j + 16 * g) * 8u;      // (16 bytes per lane, contiguous, aligned)
-    asm volatile("" : "+v"(xaddr2));
-#endif
     const lds_u4* ab = (const lds_u4*)static_cast<size_t>(aaddr);
     int pair = g;
     asm volatile("" : "+v"(pair));
@@ -300,11 +293,7 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
             constexpr int n = g0 + decltype(I)::value;
             // records f + n + 16 kk and + 64 in ONE instruction and one register quad (left to itself the compiler pairs
             // record n with n + 1 -- adjacent addresses -- and then shuffles six registers per two taps)
-#ifdef HSS_ABL_B128      // development: what ONE 16-byte read per tap would cost (wrong operands: results invalid)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[n - g0]) : "v"(xaddr2), "n"(16 * n) : "memory");
-#else
             asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(b[n - g0]) : "v"(xaddr), "n"(n), "n"(n + 64) : "memory");
-#endif
             a[n - g0] = ab[n * 64];
         });
         // (the compiler does not count LDS operations issued from inline assembly: wait for them here; its own counts for
@@ -322,18 +311,9 @@ __device__ __forceinline__ void canon_group(const u2* xrec, const float* atab, f
         __builtin_amdgcn_sched_barrier(0);
     });
     CPROBE(0);
-#if !defined(HSS_T16_PF_AT) || HSS_T16_PF_AT == 1
-    mid();
-#endif
 #if !defined(HSS_CANON_ABLATE) || HSS_CANON_ABLATE < 5
     fft_n<NT>(za);
-#if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 2
-    mid();
-#endif
     fft_n<NT>(zb);
-#endif
-#if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 3
-    mid();
 #endif
     CPROBE(1);
     // ("Offsets" above) a tile staged without its mean: + mean x the spectrum of the all-ones frame, ONE block between the spectra and

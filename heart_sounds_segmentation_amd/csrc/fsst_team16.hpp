@@ -67,52 +67,38 @@
 namespace hssfsst {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-__device__ unsigned g_t16_blk[256 * 16 * 8];             // per wave of the LAST launch: misses, looks, ticks waited, finisher ticks, signals finished
-#endif
-#ifdef HSS_T16_TLPROBE       // development (tools/timeline.py): team 0's waves log {event << 28 | signal << 8 | group, time} of the LAST launch
-constexpr int kTlCap = 512;
-__device__ unsigned g_t16_tl[16 * 16 * kTlCap * 2];
-#endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE) || defined(HSS_T16_BLKPROBE)      // development (tools/xcc_speed.py): per block {XCC_ID, start, end (100 MHz ticks), identity} of the LAST launch
-__device__ unsigned long long g_t16_xcc[256 * 4 + 8];      // [1024] statistics not there in time, [1025] further looks
-#endif
 
 constexpr int kT16PartFloats = 6;            // a group's statistics partial in the CU's LDS: S1re S2re S1im S2im p_re p_im
 constexpr int kT16BlockWords = 8;            // tagged 8-byte words per BLOCK of kStatBlock groups in the mailbox: the block's four
                                              // float64 sums (sum re, sum re^2, sum im, sum im^2), each as {high, low} half
 constexpr int kT16MaxBlocks = kFusedMaxGroups / kStatBlock;      // 32 blocks per signal
 constexpr int kT16MaxCpc = 8;                // groups of a signal per CU (two blocks)
-constexpr int kT16MaxSlots = 64;             // mailbox slots per team (signal ordinal mod slots)
-constexpr int kT16FinWords = 8;              // tagged 8-byte words per signal behind its block sums: {mean_re, 1/std_re, mean_im, 1/std_im} (+ 4 spare)
-constexpr int kT16SlotWords = kT16MaxBlocks * kT16BlockWords + kT16FinWords;      // a signal's mailbox slot
-constexpr int kT16WaveStat = 12;             // per wave, behind its canonical region: three float4 {mean, 1/std} pairs -- (re, re), (re, im), (im, im): the
-                                             // z-score of a float4 of the image reads the one its two column pairs need (cls_lds)
-constexpr int kT16StageWords = 8;            // per wave, in the block's control words: the 32-byte copy of a signal's four tagged statistics words
-                                             // (BELOW 64 KiB: the LDS target of global_load_lds is M0's sixteen bits)
-// [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets | the waves' fetched statistics words
-constexpr int t16_ctl_base() { return 16 + 64 + 192 + 2 * 16 * kT16StageWords; }
+constexpr int kT16MaxSlots = 64;             // statistics slots per CU / mailbox slots per team (signal ordinal mod slots); 32 where the LDS is short
+constexpr int kT16StatFloats = 12;           // a signal's statistics in LDS: three float4 {mean, 1/std} pairs -- (re, re), (re, im), (im, im): the
+                                             // z-score of a float4 of the image reads the one its two column pairs need (emit_held)
+// [0] ticket counter [1] dead [2] identity | statistics-table offsets | wide-store offsets | ready[slots], claim[slots] | statistics[slots][3] float4
+constexpr int t16_ctl_base(int slots) { return 16 + 64 + 192 + 2 * slots + kT16StatFloats * slots; }
 // ... then the partials of the CU's own groups, PSLOTS signals deep: [PSLOTS][kT16MaxCpc][6] floats + [PSLOTS][2] block counters
-constexpr int t16_ctl_floats(int pslots) { return t16_ctl_base() + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
+constexpr int t16_ctl_floats(int pslots, int slots) { return t16_ctl_base(slots) + pslots * (kT16MaxCpc * kT16PartFloats + 2); }
+// what the LDS beside the tables and 16 wave regions leaves: partials 32 signals deep and 64 statistics slots where they fit
 // own planes per wave: two where the LDS has room for them (the second one holds the previous step's image: "Two planes" below)
-template <int KLO, int KC>
-constexpr int t16_wave_floats(int planes) { return CanonCfg<KLO, KC>::wave_floats(planes) + kT16WaveStat; }
 #ifndef HSS_T16_PLANES
-#define HSS_T16_PLANES 2
-#endif
+#define HSS_T16_PLANES 1                     // (2: a second own plane per wave -- a third held group at no instruction; measured +0.9 % on the queued kernel,
+#endif                                       //  profiles/r06_team_waits.txt: the resolves are started by the first wave that needs them, whatever the depth)
 template <int KLO, int KC>
 constexpr int t16_planes()
 {
-    return HSS_T16_PLANES >= 2 && 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * t16_wave_floats<KLO, KC>(2) >= t16_ctl_floats(16) ? 2 : 1;
+    return HSS_T16_PLANES >= 2 && 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(2) >= t16_ctl_floats(16, kT16MaxSlots / 2) ? 2 : 1;
 }
-// what the LDS beside the tables and 16 wave regions leaves: the CU's partials 32 signals deep where they fit
 template <int KLO, int KC>
-constexpr int t16_room() { return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * t16_wave_floats<KLO, KC>(t16_planes<KLO, KC>()); }
+constexpr int t16_room() { return 160 * 1024 / 4 - kCanonLdsTabFloats - 16 * CanonCfg<KLO, KC>::wave_floats(t16_planes<KLO, KC>()); }
+template <int KLO, int KC>
+constexpr int t16_slots() { return t16_room<KLO, KC>() >= t16_ctl_floats(16, kT16MaxSlots) ? kT16MaxSlots : kT16MaxSlots / 2; }
 template <int KLO, int KC>
 constexpr int t16_pslots()
 {
-    constexpr int room = t16_room<KLO, KC>();
-    return room >= t16_ctl_floats(32) ? 32 : room >= t16_ctl_floats(16) ? 16 : 0;
+    constexpr int room = t16_room<KLO, KC>(), sl = t16_slots<KLO, KC>();
+    return room >= t16_ctl_floats(32, sl) ? 32 : room >= t16_ctl_floats(16, sl) ? 16 : 0;
 }
 
 struct Team16Params {
@@ -121,7 +107,7 @@ struct Team16Params {
     const float* atab;    // f16 operand table + float64 twiddles (kCanonAtabFloats floats), then the offset table (kCanonZcFloats)
     const double* wtab;   // float64 {w, dw'}[128]                } rounding-tie path
     const double* twtab;  // float64 {cos, sin}(2 pi m / 128)     }
-    unsigned long long* mail;   // [teams][slots][kT16SlotWords] tagged words {tag << 32 | half of a float64 block sum}: 32 blocks x 8, then the signal's four statistics
+    unsigned long long* mail;   // [teams][slots][32 blocks][8] tagged words {tag << 32 | half of a float64 block sum}
     unsigned* status;     // device status word (0 = ok)
     float r2scale_s;      // r2scale of the plan x (constant scale)^2
     float inv_c;          // 1 / constant scale
@@ -135,7 +121,7 @@ struct Team16Params {
     unsigned* arrive;     // arrival counter of the plan (monotone over launches)
     unsigned arrive_base; // its value before this launch: block identity = arrival number - arrive_base
     unsigned* abort_word; // a wait that ran out of time stores `launch` here; every wave then leaves the kernel
-    unsigned* fallbacks;  // pinned host words: [0] the same store, for the host's eyes; [1] the launch that gave up because of an offset tile
+    unsigned* fallbacks;  // pinned host word: the same store, for the host's eyes
     unsigned launch;      // identity of this launch (never 0)
     double inv_total, inv_total1;   // 1 / (K ncols), 1 / (K ncols - 1): the two divisions of stats_finish, made once on the host
 };
@@ -171,6 +157,7 @@ __device__ __forceinline__ f2 held_zscore(f2 m)
 
 // WPB waves per block (one block per CU), DEPTH group images held per wave (registers): (16, 2) is what the library launches
 template <int KLO, int KC, int WPB, int DEPTH>
+// (amdgpu_num_vgpr(52): the attribute counts in register PAIRS on this target -- 104 allocatable registers; v104 .. v127 are the held images')
 __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(52))) void fsst_team16_kernel(Team16Params p)
 {
     using C = CanonCfg<KLO, KC>;
@@ -186,28 +173,25 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     unsigned* dead = reinterpret_cast<unsigned*>(smem + ATAB) + 1;
     unsigned* cls_lds = reinterpret_cast<unsigned*>(smem + ATAB + 16);       // [64] byte i: which of a signal's three float4 statistics float4 lane + 64 i reads
     unsigned* ppk_lds = reinterpret_cast<unsigned*>(smem + ATAB + 80);       // [3][64]
-    constexpr int PSLOTS = t16_pslots<KLO, KC>();
+    unsigned* ready = reinterpret_cast<unsigned*>(smem + ATAB + 272);        // [slots] epoch (signal ordinal + 1) of the statistics in fin[]
+    constexpr int MS = t16_slots<KLO, KC>(), PSLOTS = t16_pslots<KLO, KC>();
+    unsigned* claim = ready + MS;                                            // [slots] epoch some wave of this CU is resolving / has resolved
+    float4* fin = reinterpret_cast<float4*>(smem + ATAB + 272 + 2 * MS);     // [slots][3]
     static_assert(PSLOTS >= 16, "the CU's own partials need LDS beside the wave regions");
-    float* part_lds = smem + ATAB + t16_ctl_base();                          // [PSLOTS][kT16MaxCpc][6]
+    float* part_lds = smem + ATAB + t16_ctl_base(MS);                        // [PSLOTS][kT16MaxCpc][6]
     int* pcnt_lds = reinterpret_cast<int*>(part_lds + PSLOTS * kT16MaxCpc * kT16PartFloats);   // [PSLOTS][2] partials delivered per block
     constexpr int PLANES = t16_planes<KLO, KC>();
-    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS) + wv * t16_wave_floats<KLO, KC>(PLANES);
+    float* wbase = smem + ATAB + t16_ctl_floats(PSLOTS, MS) + wv * C::wave_floats(PLANES);
     u2* xrec = reinterpret_cast<u2*>(wbase);
     f2* own_first = reinterpret_cast<f2*>(wbase + 2 * kCanonRecs);
     int* flag = reinterpret_cast<int*>(own_first + PLANES * 16 * C::LD);
     int* tq = flag + kCanonFlagWords;
-    unsigned* stage = reinterpret_cast<unsigned*>(smem + ATAB + 272) + wv * kT16StageWords;   // [8] the fetched statistics words {value, tag} x 4 (16-byte aligned)
-    float4* wstat = reinterpret_cast<float4*>(tq + kCanonTieWords);          // [3] this wave's z-score table of the group that leaves
-    unsigned* stage2 = stage + 16 * kT16StageWords;                          // [8] the second look: asked for behind the transform
-    static_assert(WPB <= 16 && (ATAB + 272 + 2 * 16 * kT16StageWords) * 4 < 65536, "global_load_lds targets sit in the first 64 KiB");
-    static_assert((2 * kCanonRecs + PLANES * 2 * 16 * C::LD + kCanonFlagWords + kCanonTieWords) % 4 == 0 && t16_wave_floats<KLO, KC>(PLANES) % 4 == 0 &&
-                  (ATAB + t16_ctl_floats(PSLOTS)) % 4 == 0, "the statistics words are the target of a 16-byte copy");
 
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
     if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
-    if (lane < 8) { stage[lane] = 0u; stage2[lane] = 0u; }                   // (no tag is 0)
+    for (int i = threadIdx.x; i < 2 * MS; i += 64 * WPB) ready[i] = 0u;       // ready[], claim[]
     if (threadIdx.x < 2 * PSLOTS) pcnt_lds[threadIdx.x] = 0;
     // Block identity = ARRIVAL number ("Giving up" above)
     if (threadIdx.x == 64)
@@ -252,18 +236,12 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
 
     // ---- team geometry (wave-uniform): T consecutive identities form a team
     const int virt = __builtin_amdgcn_readfirstlane(next_q[2]);
-#ifdef HSS_T16_XCCPROBE
-    const unsigned long long xcc_t0 = wall_clock64();
-#endif
     // an identity outside the grid = arrivals of two launches of one plan interleaved (a plan is single-stream: hssfsst.h):
     // give the launch up instead of indexing outside the mailboxes (the gated fallback computes the exec)
     if (static_cast<unsigned>(virt) >= gridDim.x) { gave_up(); return; }
     if (aborted()) return;                               // (a block that starts after the launch was given up)
     const int T = p.team, cpcs = p.cpc_shift, cpc = 1 << cpcs;
     const int member = virt & (T - 1), team = virt / T;
-#ifdef HSS_T16_INTERLEAVE
-    const int tsh = __builtin_ctz(static_cast<unsigned>(T));
-#endif
     const int nteams = static_cast<int>(gridDim.x) / T;
     const int nk = (p.nsig > team) ? (p.nsig - team + nteams - 1) / nteams : 0;      // signals of this team
     const int nwork = nk << cpcs;
@@ -271,29 +249,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     const int G = (ncols + 15) >> 4;
     const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     const int smask = p.slots - 1;
-    constexpr int nwords = kT16SlotWords;                      // tagged words per signal in the mailbox
+    constexpr int nwords = kT16MaxBlocks * kT16BlockWords;     // tagged words per signal in the mailbox
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * nwords;
     const int nblocks = (G + kStatBlock - 1) / kStatBlock;
     const unsigned sig_bytes = static_cast<unsigned>(ncols) * (2 * K * 4);         // a signal's feature block (at most 128 groups: 32 bits)
 
     f2 tiny = {1.0e-37f, 0.0f};
     asm volatile("" : "+s"(tiny));
-#ifdef HSS_T16_TLPROBE
-    int tl_n = 0;
-    auto TL = [&](unsigned ev, int ko_e, int g_e) {
-        if (team == 0 && tl_n < kTlCap) {
-            const unsigned t = static_cast<unsigned>(wall_clock64());
-            if (lane == 0) {
-                unsigned* e = g_t16_tl + ((member * 16 + wv) * kTlCap + tl_n) * 2;
-                e[0] = (ev << 28) | (static_cast<unsigned>(ko_e) << 8) | static_cast<unsigned>(g_e);
-                e[1] = t;
-            }
-            ++tl_n;
-        }
-    };
-#else
-    auto TL = [&](unsigned, int, int) {};
-#endif
 
     // ---- draw: the next group of this CU's list and its tile's samples on their way into registers
     float sreg[3];
@@ -325,14 +287,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         while (qi < nwork) {
             q_last = qi;
             ko_d = qi >> cpcs;
-#ifdef HSS_T16_INTERLEAVE
-            {   // CU c' = (member + ko) mod T takes the BLOCKS c', c' + T, .. of the signal (a block = kStatBlock consecutive groups)
-                const int pos_d = qi & (cpc - 1);
-                g_d = ((((member + ko_d) & (T - 1)) + T * (pos_d >> 2)) << 2) + (pos_d & 3);
-            }
-#else
             g_d = (((member + ko_d) & (T - 1)) << cpcs) + (qi & (cpc - 1));       // CU c' = (member + ko) mod T: groups cpc c' ..
-#endif
             if (g_d < G) { d_valid = true; break; }
             if (lane == 0) qi = __hip_atomic_fetch_add(next_q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             qi = __builtin_amdgcn_readfirstlane(qi);
@@ -347,29 +302,30 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     };
     auto draw = [&](int after_ko) { draw_ask(after_ko); draw_take(); };
 
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-    unsigned pb_miss = 0u, pb_looks = 0u, pb_blocked = 0u, pb_fin = 0u, pb_nfin = 0u;
-#endif
-#ifdef HSS_T16_MISSPROBE     // development: how many groups leave without their statistics being there (one counter, one atomic per wave)
-    unsigned pm_miss = 0u, pm_all = 0u;
-#endif
-    // ---- Statistics of signal ordinal ko (of this team): {mean_re, 1/std_re, mean_im, 1/std_im}, ONCE per signal and team, pushed.
+    auto stats_ready = [&](int ko) -> bool {             // the CU already has this signal's statistics
+        unsigned have = 0u;
+        if (lane == 0) have = __hip_atomic_load(ready + (ko & smask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(have)) == static_cast<unsigned>(ko) + 1u;
+    };
+    auto try_claim = [&](int ko) -> bool {
+        unsigned mine = 0u;
+        const unsigned epoch = static_cast<unsigned>(ko) + 1u;
+        if (lane == 0) mine = __hip_atomic_fetch_max(claim + (ko & smask), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch ? 1u : 0u;
+        return __builtin_amdgcn_readfirstlane(mine) != 0u;
+    };
+
+    // ---- Statistics of signal ordinal ko (of this team): {mean_re, 1/std_re, mean_im, 1/std_im}, once per signal and CU.
     // The mailbox holds the signal's BLOCK sums -- float64 {sum re, sum re^2, sum im, sum im^2} of every block of kStatBlock groups,
     // formed by the CU that transformed the block with the arithmetic of signal_stats()' inner loop (piece_moment, pieces in order)
-    // -- as tagged halves.  The wave that publishes the signal's LAST block (block nblocks - 1: one wave per signal and team) stays
-    // and finishes: lane (blk % 16, q) fetches quantity q of the blocks blk and blk + 16 (its 16-byte pairs l and l + 64: the mailbox
-    // is laid out for exactly that) until they are all there, adds them in that order and runs stats_finish -- the instructions of
-    // stats_from_blocks() on the numbers of the two-launch path -- and leaves the four results as tagged words behind the block sums.
-    // (Rounds 4-5 resolved per CU and on demand: the first wave of a CU that could not go on without a signal's statistics claimed
-    //  it, fetched the block sums and finished, its up to fifteen siblings waited for it -- sixteen resolves per signal, each STARTED
-    //  by the first wave that needed its result, whatever the depth of the held groups: 12 % of the queued kernel, profiles/r06_push_stats.txt.)
-    // (the look at the block sums: until they are all there; the result -- stats_finish's four numbers -- in lane 0)
-    auto resolve_blocks = [&](int ko) __attribute__((always_inline)) -> float4 {
-        int lane_r = lane;
-        asm volatile("" : "+v"(lane_r));
-        const unsigned t0 = static_cast<unsigned>(wall_clock64());
+    // -- as tagged halves.  Lane (blk % 16, q) of the wave that has claimed the signal fetches quantity q of the blocks blk and
+    // blk + 16 (its 16-byte pairs l and l + 64: the mailbox is laid out for exactly that), adds them in that order and runs
+    // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.
+    // the claim is this wave's: look at the mailbox until both of the lane's blocks are there
+    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) {
+        // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
+        __builtin_amdgcn_s_setprio(3);
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
-        const gu64* slotp = mail + static_cast<size_t>(ko & smask) * nwords;
+        const gu64* slot = mail + static_cast<size_t>(ko & smask) * nwords;
         const int blk0 = lane_r >> 2;
         unsigned need = (blk0 < nblocks ? 1u : 0u) | (blk0 + 16 < nblocks ? 2u : 0u);
         double sb[2] = {0.0, 0.0};
@@ -377,7 +333,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 if ((need >> rb) & 1u) {
-                    const gu64* q = slotp + 2 * (lane_r + 64 * rb);
+                    const gu64* q = slot + 2 * (lane_r + 64 * rb);
                     const unsigned long long hi = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long lo = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (static_cast<unsigned>(hi >> 32) == tag && static_cast<unsigned>(lo >> 32) == tag) {
@@ -387,134 +343,45 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 }
             if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) break;
             if ((polls & 7u) == 7u && expired(t0)) { gave_up(); leave(); }
-            if (is_dead()) leave();
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(8);
         }
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-        pb_fin += static_cast<unsigned>(wall_clock64()) - t0; ++pb_nfin;
-#endif
         // stats_from_blocks(): lane (blk % 16, q) adds its blocks blk, blk + 16 in that order, then stats_finish
         double acc = 0.0;
         if (blk0 < nblocks) acc += sb[0];
         if (blk0 + 16 < nblocks) acc += sb[1];
         static_assert(kT16MaxBlocks <= 32, "a lane sums at most two blocks");
-        return stats_finish_lead(acc, P()->inv_total, P()->inv_total1, lane_r);
-    };
-    auto finish_signal = [&](int ko) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(3);
-        TL(2u, ko, 0);
-        const float4 r = resolve_blocks(ko);
-        TL(3u, ko, 0);
-        const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
+        const float4 r = stats_finish_lead(acc, P()->inv_total, P()->inv_total1, lane_r);
         if (lane == 0) {
-            gu64* f = mail + static_cast<size_t>(ko & smask) * nwords + kT16MaxBlocks * kT16BlockWords;
-            const unsigned long long th = static_cast<unsigned long long>(tag) << 32;
-            __hip_atomic_store(f + 0, th | __float_as_uint(r.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(f + 1, th | __float_as_uint(r.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(f + 2, th | __float_as_uint(r.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(f + 3, th | __float_as_uint(r.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // A wave asks for the statistics of the group that will leave at the end of its step from the middle of the transform: a 32-byte
-    // copy of the signal's four tagged words straight into the wave's LDS (global_load_lds: no register is held across the transform;
-    // agent scope, as every look at the mailbox).  The step's one wait for memory behind the transform covers it.
-    // (From inline assembly: behind the builtin the compiler's wait-count pass puts an s_waitcnt vmcnt(0) in front of the next LDS
-    //  operation it cannot tell apart from the copy's target -- the transform's first store into the plane, a hundred instructions on:
-    //  the whole trip to the mailbox waited for in every group, +20 % on the kernel.  Nothing reads `stage` before the explicit wait.)
-    const unsigned stage_lds = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned*)stage))));
-    auto stats_prefetch = [&](int ko, unsigned target_lds) {
-        const gu64* f = mail + static_cast<size_t>(ko & smask) * nwords + kT16MaxBlocks * kT16BlockWords;
-        if (lane < 2) {
-            const gu64* fl = f + 2 * lane;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(fl), "s"(target_lds) : "m0", "memory");
-        }
-    };
-    // The statistics of signal ko into this wave's z-score table: from the words the wave asked for in time (the rule), else by
-    // looking at the mailbox until they are there -- every wait bounded; a wave that finds the launch given up does not come back.
-    auto stats_take = [&](int ko, bool look2 = false) __attribute__((always_inline)) {
-        int lane_r = lane;
-        asm volatile("" : "+v"(lane_r));
-        const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
-        const u4* st4 = reinterpret_cast<const u4*>(stage);
-        const u4 a = st4[0], b = st4[1];                 // (every lane the same 32 bytes: broadcast reads)
-        const bool ok = a.y == tag && a.w == tag && b.y == tag && b.w == tag;
-#ifdef HSS_T16_MISSPROBE
-        ++pm_all; if (__builtin_amdgcn_readfirstlane(ok ? 1 : 0) == 0) ++pm_miss;
-#endif
-#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE >= 1      // development: nobody waits for the statistics (1, 2: nobody finishes either; results invalid)
-        if (true) {
-#else
-        if (__builtin_expect(__builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0, 1)) {
-#endif
-            TL(4u, ko, 0);
-            if (lane_r < 3) {
-                const unsigned x = lane_r == 2 ? b.x : a.x, y = lane_r == 2 ? b.z : a.z, z = lane_r == 0 ? a.x : b.x, w = lane_r == 0 ? a.z : b.z;
-                wstat[lane_r] = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
-#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE == 4       // development: nobody waits, the z-score runs on PLAUSIBLE statistics (the stored data look like features)
-                if (!ok) wstat[lane_r] = make_float4(0.01f, 3.0f, -0.02f, 2.5f);
-#endif
-            }
-        } else {
-            TL(5u, ko, 0);
-            // not there in time: the team's finisher is still at it, or its words are still on their way
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-            ++pb_miss;
-            const unsigned tb0 = static_cast<unsigned>(wall_clock64());
-#endif
-#ifdef HSS_T16_MISS_BLOCKS   // development: the early wave finishes from the block sums itself (heavier looks: measured slower, profiles/r06_push_stats.txt)
-            __builtin_amdgcn_s_setprio(3);
-            const float4 r = resolve_blocks(ko);
-            __builtin_amdgcn_s_setprio(0);
-            TL(6u, ko, 0);
-            if (lane == 0) {
-                wstat[0] = make_float4(r.x, r.y, r.x, r.y);
-                wstat[1] = make_float4(r.x, r.y, r.z, r.w);
-                wstat[2] = make_float4(r.z, r.w, r.z, r.w);
-            }
-#else
-            // the second look (asked for behind the transform) first, then looks at the signal's four words until they are there (four lanes,
-            // eight bytes each: a light look)
-            const unsigned t0 = static_cast<unsigned>(wall_clock64());
-            const gu64* f = mail + static_cast<size_t>(ko & smask) * nwords + kT16MaxBlocks * kT16BlockWords;
-            u4 a2, b2;
-            bool have2 = false;
-#ifndef HSS_T16_NO_LOOK2
-            if (look2) {
-                if (d_valid) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const u4* s24 = reinterpret_cast<const u4*>(stage2);
-                a2 = s24[0]; b2 = s24[1];
-                have2 = a2.y == tag && a2.w == tag && b2.y == tag && b2.w == tag;
-                have2 = __builtin_amdgcn_readfirstlane(have2 ? 1 : 0) != 0;
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-                if (have2) ++pb_looks;
-#endif
-            }
-#endif
-            for (unsigned tries = 0; !have2; ++tries) {
-                if (lane_r < 4) {
-                    const unsigned long long w = __hip_atomic_load(f + lane_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    reinterpret_cast<unsigned long long*>(stage)[lane_r] = w;
-                }
-                wave_sync();
-                a2 = st4[0]; b2 = st4[1];
-                const bool ok2 = a2.y == tag && a2.w == tag && b2.y == tag && b2.w == tag;
-                if (__builtin_amdgcn_readfirstlane(ok2 ? 1 : 0) != 0) break;
-                if ((tries & 3u) == 3u && expired(t0)) { gave_up(); leave(); }
-                if (is_dead()) leave();
-                __builtin_amdgcn_s_sleep(4);
-            }
-            TL(6u, ko, 0);
-            if (lane_r < 3) {
-                const unsigned x = lane_r == 2 ? b2.x : a2.x, y = lane_r == 2 ? b2.z : a2.z, z = lane_r == 0 ? a2.x : b2.x, w = lane_r == 0 ? a2.z : b2.z;
-                wstat[lane_r] = make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
-            }
-#endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-            pb_blocked += static_cast<unsigned>(wall_clock64()) - tb0;
-#endif
+            float4* f3 = fin + 3 * (ko & smask);
+            f3[0] = make_float4(r.x, r.y, r.x, r.y);
+            f3[1] = make_float4(r.x, r.y, r.z, r.w);
+            f3[2] = make_float4(r.z, r.w, r.z, r.w);
+            __hip_atomic_store(ready + (ko & smask), static_cast<unsigned>(ko) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         wave_sync();
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // a wave cannot go on without a signal's statistics: a sibling's result, or this wave resolves (a wave that finds the launch
+    // given up does not come back)
+    auto signal_statistics = [&](int ko) {
+#if defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2)      // development: nobody waits, nobody resolves (results invalid)
+        return;
+#endif
+        if (stats_ready(ko)) return;
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
+        const unsigned t0 = static_cast<unsigned>(wall_clock64());
+#if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE == 3      // development: the resolver resolves, nobody else waits (results invalid)
+        if (try_claim(ko)) resolve_owned(ko, t0, lane_r);
+        return;
+#endif
+        for (unsigned spins = 0;; ++spins) {
+            if ((spins & 15u) == 0u && try_claim(ko)) { resolve_owned(ko, t0, lane_r); return; }
+            if ((spins & 31u) == 31u && expired(t0)) { gave_up(); leave(); }
+            if (is_dead()) leave();
+            __builtin_amdgcn_s_sleep(4);
+            if (stats_ready(ko)) return;
+        }
     };
 
     // z-score of a held group from registers -- (v - mean) * (1 / std), two roundings, exactly as fsst_normalize_kernel -- and
@@ -525,8 +392,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         constexpr int sl = decltype(SL)::value;
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const unsigned cofs = cls_lds[lane_r];
-        const char* tb = reinterpret_cast<const char*>(wstat);
+        const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_h & smask));
         char* obase = reinterpret_cast<char*>(P()->out) + static_cast<unsigned long long>(static_cast<unsigned>(team + ko_h * nteams)) * sig_bytes +
                       static_cast<unsigned>(g_h * (16 * 2 * K * 4));                                                          // (wave-uniform)
         const unsigned voff = static_cast<unsigned>(lane_r) * 16u;
@@ -585,9 +453,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         ko = ko_d; g = g_d; c_valid = true; d_valid = false;
     };
     int slot = 0;                                        // the slot this step fills (steps take the slots in turn)
-#ifdef HSS_T16_LATE_DRAW
-    bool t16_late = false;
-#endif
     // Two planes (where the LDS has them: the displaced plane's 47 kB, fsst_canon128.hpp "One plane").  The steps write the planes in
     // turn, and a step's image stays in its plane for a whole step: it moves into the registers at the END OF THE NEXT step, when the
     // other plane holds that step's image.  A group's statistics are therefore wanted THREE steps after its partial was published
@@ -618,20 +483,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
         }
 #endif
-        TL(7u, ko, g);
         f2* own_base = own_first + cur * (16 * C::LD);
-        // the group that leaves at the end of this step (the one in this step's slot, once the wave holds DEPTH groups and -- two planes -- an
-        // image waits in the other plane): its signal's statistics are asked for from the middle of the transform
-        int pf_ko = -1;
-        if (nheld == DEPTH && (PLANES == 1 || p_valid))
-            static_for<DEPTH>([&](auto S) { if (slot == decltype(S)::value) pf_ko = ko_hs[decltype(S)::value]; });
-        auto mid = [&]() { if (pf_ko >= 0) stats_prefetch(pf_ko, stage_lds); };
-#if defined(HSS_T16_PF_AT) && HSS_T16_PF_AT == 0
-        mid();
-#endif
         canon_group<KLO, KC, HSS_T16_TAPB, true>(xrec + ((g + cg0) & 3) * 16, atab, own_base, flag, tq, P()->wtab, P()->twtab, tile, tiny, lane_o,
-                                           [&]() -> const float* { return P()->x + static_cast<unsigned long long>(b) * static_cast<unsigned>(P()->xstride); }, n, tg, P()->atab + kCanonAtabFloats,
-                                           nullptr, mid);
+                                           [&]() -> const float* { return P()->x + static_cast<unsigned long long>(b) * static_cast<unsigned>(P()->xstride); }, n, tg, P()->atab + kCanonAtabFloats);
         const float inv_cur = tile.inv;
         const int ko_cur = ko, g_cur = g;
         c_valid = false;
@@ -640,12 +494,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         // stores were issued: its wait-count pass merges what may be pending over every path through the loop, and a register reload
         // inside the transform's rare paths made it protect the fold's registers at the head of the loop (HSS_RARE_VMEM_DONE, fsst_canon128.hpp).
         HSS_RARE_VMEM_DONE();
-#ifndef HSS_T16_NO_LOOK2
-        // a second look, asked for here and looked at only if the first one came too early: most waves that are early are early by less than
-        // the trip this look has already made when the group leaves (stats_take waits for it with a counted s_waitcnt: the next tile's three
-        // sample loads are younger)
-        if (pf_ko >= 0) stats_prefetch(pf_ko, stage_lds + 16u * kT16StageWords * 4u);
-#endif
         if (d_valid) land();
         // ---- statistics partial -> the CU's LDS (rows 0..3 of the wave hold S1re / S2re / S1im / S2im, every lane the pivot); the
         //      wave that delivers a block's last partial forms the block's float64 sums -- signal_stats()' inner loop: the block's
@@ -654,11 +502,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             const int nvalid = min(16, cend - tg);
             f2 piv;
             const float w = canon_stats<KLO, KC>(own_base, nvalid, inv_cur, lane_o, piv);
-#ifdef HSS_T16_INTERLEAVE
-            const int pos = (((g_cur >> 2) >> tsh) << 2) | (g_cur & 3);
-#else
             const int pos = g_cur & (cpc - 1);           // position among the CU's groups of this signal
-#endif
             const int ps = ko_cur & (PSLOTS - 1);
             float* pe = part_lds + (ps * kT16MaxCpc + pos) * kT16PartFloats;
             // the first lane of each row writes its row's sum, lane 0 the pivot pair: two stores under literal exec masks (the
@@ -670,18 +514,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             const unsigned pa = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)pe)) + (static_cast<unsigned>(lane_o) >> 4) * 4u;
             const unsigned pcnt_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)(pcnt_lds + 2 * ps + (pos >> 2))));
             int before = 0;
-            // (the wave that has just landed a signal's LAST group will finish that signal for the team -- finish_signal, a wait for every
-            //  block of it -- behind that group's transform: it draws no further ticket now, so that it holds nothing unpublished while it
-            //  waits.  A finisher with a landed group of signal k + 1 made k + 1 wait for k + one transform, and so on down the list:
-            //  the signals completed one transform apart instead of every half, +20 % on the kernel.)
-            const bool fin_next = (c_valid && g == G - 1) || g_cur == G - 1;     // (the finisher itself draws behind finish_signal)
-#ifdef HSS_T16_LATE_DRAW     // the next ticket is drawn BEHIND the step's possible wait for statistics: a wave that waits holds one unpublished group, not two
-            const bool known = false;
-            const bool late_draw = !fin_next;
-#else
-            const bool known = ((q_last + 1) >> cpcs) > ko_cur && !fin_next;
-            constexpr bool late_draw = false;
-#endif
+            const bool known = ((q_last + 1) >> cpcs) > ko_cur;
             if (__builtin_expect(known, 1)) {
                 const unsigned nq_a = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) int*)next_q));
                 unsigned one = 1u, before_v, qi_v, dd_v;
@@ -703,10 +536,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                              : "=&s"(keep) : "v"(pa), "v"(w), "v"(piv) : "memory");
                 wave_sync();
                 if (lane == 0) before = __hip_atomic_fetch_add(pcnt_lds + 2 * ps + (pos >> 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (fin_next || late_draw) { ask_qi = 0x7fffffff; ask_dd = 0u; if (lane == 0) ask_dd = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-                else draw_ask(ko_cur);
+                draw_ask(ko_cur);
             }
-            TL(1u, ko_cur, g_cur);
             const int blk = g_cur >> 2, bfirst = blk << 2;                       // kStatBlock = 4
             const int expect = min(kStatBlock, G - bfirst);
             if (__builtin_amdgcn_readfirstlane(before) + 1 == expect) {
@@ -743,13 +574,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
-#if !(defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2))
-            if (g_cur == G - 1) finish_signal(ko_cur);       // (the signal's last group: this wave finishes the signal for the team)
-#endif
-            if (g_cur == G - 1 && !(c_valid && g == G - 1)) draw_ask(ko_cur);
-#ifdef HSS_T16_LATE_DRAW
-            t16_late = late_draw;
-#endif
         }
         draw_take();
         // ---- this step's slot: the group that sits there (the oldest the wave holds) leaves, the new group's image moves in.
@@ -766,16 +590,18 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             asm volatile("" : "+v"(lane_r));
             const unsigned cofs = cls_lds[lane_r];
             const unsigned pk0 = ppk_lds[lane_r], pk1 = ppk_lds[64 + lane_r], pk2 = ppk_lds[128 + lane_r];
-            if (full) stats_take(ko_o, pf_ko == ko_o); else ++nheld;
+            const unsigned have = __hip_atomic_load(ready + (ko_o & smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (every lane: a broadcast read)
+            if (full) {
+#if !(defined(HSS_T16_ABLATE) && (HSS_T16_ABLATE == 1 || HSS_T16_ABLATE == 2))
+                if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(have))) != static_cast<unsigned>(ko_o) + 1u) signal_statistics(ko_o);
+#endif
+            } else ++nheld;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             unsigned obase = static_cast<unsigned>(reinterpret_cast<size_t>((lds_float*)reinterpret_cast<const float*>(src_plane)));
             asm volatile("" : "+s"(obase));
             auto cell = [&](unsigned off) -> f2 {
-#ifdef HSS_ABL_NOGATHER      // development: the image without its twelve LDS reads (results invalid)
-                return f2{__uint_as_float(off + obase), inv_cur};
-#else
                 const lds_float* q = (const lds_float*)static_cast<size_t>(obase + off);
                 return f2{q[0], q[2]};
-#endif
             };
             const f2 lo0 = cell(pk0 & 0xffffu), hi0 = cell(pk0 >> 16), lo1 = cell(pk1 & 0xffffu), hi1 = cell(pk1 >> 16),
                      lo2 = cell(pk2 & 0xffffu), hi2 = cell(pk2 >> 16);
@@ -784,7 +610,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
                 constexpr int sl = decltype(S)::value;
                 if (slot == sl) {
                     if (full) {
-                        const char* tb = reinterpret_cast<const char*>(wstat);
+                        const char* tb = reinterpret_cast<const char*>(fin + 3 * (ko_o & smask));
                         const float4 t0 = *reinterpret_cast<const float4*>(tb + (cofs & 0xffu));
                         const float4 t1 = *reinterpret_cast<const float4*>(tb + ((cofs >> 8) & 0xffu));
                         const float4 t2 = *reinterpret_cast<const float4*>(tb + ((cofs >> 16) & 0xffu));
@@ -830,9 +656,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         } else
             move_in(own_base, inv_cur, ko_cur, g_cur);
         wave_sync();
-#ifdef HSS_T16_LATE_DRAW
-        if (t16_late && !d_valid) draw(ko_cur);
-#endif
     }
     // ---- the list is done: the image that still sits in its plane moves in (the oldest held group leaves for it) ...
     if constexpr (PLANES == 2) {
@@ -842,7 +665,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             (void)g_o;
             const f2* src_plane = own_first + (cur ^ 1) * (16 * C::LD);
             const bool full = nheld == DEPTH;
-            if (full) stats_take(ko_o); else ++nheld;
+            if (full) signal_statistics(ko_o); else ++nheld;
             static_for<DEPTH>([&](auto S) {
                 constexpr int sl = decltype(S)::value;
                 if (slot == sl) {
@@ -870,30 +693,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         const int so = (slot + DEPTH - nheld + i) % DEPTH;
         static_for<DEPTH>([&](auto S) {
             constexpr int sl = decltype(S)::value;
-            if (so == sl) { stats_take(ko_hs[sl]); emit_held(S, ko_hs[sl], g_hs[sl]); }
+            if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(S, ko_hs[sl], g_hs[sl]); }
         });
     }
-#ifdef HSS_T16_MISSPROBE
-    if (lane == 0) {
-        __hip_atomic_fetch_add(&g_t16_xcc[1024], static_cast<unsigned long long>(pm_miss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&g_t16_xcc[1025], static_cast<unsigned long long>(pm_all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-    if (lane == 0 && virt < 256) {      // (one slot per wave: 4096 waves adding to five words took longer than the kernel)
-        unsigned* e = g_t16_blk + (virt * 16 + wv) * 8;
-        e[0] = pb_miss; e[1] = pb_looks; e[2] = pb_blocked; e[3] = pb_fin; e[4] = pb_nfin;
-    }
-#endif
-#ifdef HSS_T16_XCCPROBE
-    if (lane == 0 && virt < 256) {      // (the last wave of the block to get here leaves the latest end)
-        const unsigned long long t1 = wall_clock64();
-        g_t16_xcc[4 * virt + 0] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) | (static_cast<unsigned long long>(blockIdx.x) << 8);
-        g_t16_xcc[4 * virt + 1] = xcc_t0;
-        __hip_atomic_fetch_max(&g_t16_xcc[4 * virt + 2], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        g_t16_xcc[4 * virt + 3] = static_cast<unsigned long long>(virt);
-    }
-#endif
 }
 
 }  // namespace hssfsst

@@ -25,7 +25,6 @@
 #include "fsst_mfma128.hpp"
 #include "fsst_canon128.hpp"
 #include "fsst_team16.hpp"
-#include "fsst_teamq.hpp"
 #ifndef HSS_T16_WPB
 #define HSS_T16_WPB 16
 #define HSS_T16_DEPTH 2
@@ -65,7 +64,6 @@ struct DebugSwitches {
     bool no_canon = false;        // the canonical band on the general kernels (fsst_mfma128.hpp)
     bool no_team = false;         // never the team kernel
     bool team_only = false;       // the team kernel or two launches, never one CU per signal
-    bool team_static = false;     // the team kernel with a fixed share of every signal per CU (fsst_team16_kernel; A/B)
     bool team_force_fallback = false;   // every team launch finds itself given up (tests of the gated fallback)
     bool force_dft = false;       // every window length on the any-length kernel
     bool force_generic = false;   // every radix length on the generic VALU kernel
@@ -87,7 +85,7 @@ const DebugSwitches& debug_switches()
             const int iv = val ? std::atoi(val) : 0;
             const bool on = !val || val[0] == '\0' || iv != 0 || val[0] == 'y' || val[0] == 't';
             if (key == "no_fused") d.no_fused = on; else if (key == "no_canon") d.no_canon = on;
-            else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on; else if (key == "team_static") d.team_static = on;
+            else if (key == "no_team") d.no_team = on; else if (key == "team_only") d.team_only = on;
             else if (key == "team_force_fallback") d.team_force_fallback = on; else if (key == "force_dft") d.force_dft = on;
             else if (key == "force_generic") d.force_generic = on; else if (key == "no_mfma256") d.no_mfma256 = on;
             else if (key == "split_stats") d.split_stats = on; else if (key == "no_stream_fuse") d.no_stream_fuse = on; else if (key == "no_pair") d.no_pair = on; else if (key == "team") d.team = iv;
@@ -243,10 +241,6 @@ struct hssfsst_plan {
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
     unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
-    unsigned* d_tickets = nullptr; size_t tickets_cap = 0;   // fsst_teamq_kernel: [2][teams] ticket counters, used in turn (tick_par)
-    int tick_par = 0;
-    unsigned long long* d_mailq = nullptr; size_t mailq_cap = 0;   // fsst_teamq_kernel: mailboxes [teams][slots][8 G + 8] (8-byte words)
-    unsigned teamq_seq = 0;
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
@@ -267,6 +261,8 @@ struct hssfsst_plan {
     // kernels read and write in place
     float* h_xpin = nullptr; float* d_xpin = nullptr; size_t xpin_cap = 0;
     float* h_opin = nullptr; float* d_opin = nullptr; size_t opin_cap = 0;
+    struct PinBuf { float* h; float* d; size_t cap; bool used; };
+    std::vector<PinBuf> pin_pool;                        // hssfsst_exec_pinned: pinned, device-mapped result buffers lent to the caller
     bool defer_fallback = false;                             // this exec synchronises before it returns: no gated launches behind a team launch,
     unsigned deferred_launch = 0, deferred_first = 0;        // the host looks at the pinned give-up word afterwards and redoes the exec itself
     long long* d_starts = nullptr; size_t starts_cap = 0;    // frame-list staging (hssfsst_exec_list with host starts)
@@ -550,8 +546,8 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (G < 1 || G > kFusedMaxGroups) return 0;             // (the resolver's LDS copy of a signal's partials: 128 groups)
     // (at least 84 KiB: one block per CU whatever its size -- the teams count on it)
     constexpr int PSLOTS = t16_pslots<KLO, KC>();        // signals whose partials a CU keeps in LDS at a time
-    constexpr int MS = kT16MaxSlots;                     // mailbox slots per team (global memory)
-    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS) + static_cast<size_t>(WPB) * t16_wave_floats<KLO, KC>(t16_planes<KLO, KC>())) * sizeof(float);
+    constexpr int MS = t16_slots<KLO, KC>();             // statistics / mailbox slots the kernel's LDS has room for
+    size_t lds = (kCanonLdsTabFloats + t16_ctl_floats(PSLOTS, MS) + static_cast<size_t>(WPB) * CanonCfg<KLO, KC>::wave_floats(t16_planes<KLO, KC>())) * sizeof(float);
     if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
     if (lds < 84 * 1024) lds = 84 * 1024;
     auto kern = fsst_team16_kernel<KLO, KC, WPB, DEPTH>;
@@ -576,8 +572,11 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     while (cpc * T < G) { cpc *= 2; ++cpc_shift; }
     if (cpc > WPB || cpc > kT16MaxCpc || G / T < 1) return 0;
     if (cpc < 4 && T > 1) return 0;                      // (a CU publishes whole blocks of four groups: HSSFSST_TEAM beyond G / 4)
-    const int grid = (pl->team16_cus / T) * T;
-    const int nteams = grid / T;
+    // as many teams as the chip has room for, but no more than there are signals: the dataset loop's one frame per call
+    // (/root/reference/hss/datasets/heart_sounds.py:166-168) starts one team's 16 blocks, not 256 of which 240 find nothing to do
+    int nteams = pl->team16_cus / T;
+    if (batch < nteams) nteams = static_cast<int>(batch);
+    const int grid = nteams * T;
     if ((batch + nteams - 1) / nteams > 65535) return 0;
     if (cp.xstride < 1 || cp.xstride > 0x7fffffffLL || batch > 0x7fffffffLL) return 0;      // (the kernel's 32-bit signal index and stride)
     // slots: a CU runs at most held_pos list positions ahead of its oldest unresolved signal = lead signals; a slot is reused
@@ -590,7 +589,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (lead + 1 > PSLOTS) return 0;                     // (very short signals: more signals in flight per CU than its LDS keeps partials for)
     int rc;
     if ((rc = ensure_status(pl)) != 0) return rc;
-    const size_t words = static_cast<size_t>(nteams) * slots * kT16SlotWords;
+    const size_t words = static_cast<size_t>(nteams) * slots * kT16MaxBlocks * kT16BlockWords;
     if (words > pl->mail_cap) {
         if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
         HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
@@ -622,92 +621,6 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
     pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
     name_kernel(pl, WPB, grid, "fsst_team16_kernel<%d, %d, %d, %d> teams of %d", KLO, KC, WPB, DEPTH, T);
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, tp);
-    HIP_TRY(hipGetLastError());
-    return 1;
-}
-
-// Team kernel with the work handed out per team (fsst_teamq.hpp): one ticket counter per team, a group's partial straight to the mailbox,
-// one finisher per signal.  Returns 1 when it launched, 0 when this exec should take another path, < 0 on error.
-template <int KLO, int KC, int WPB, int DEPTH>
-int launch_teamq(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t batch, int ngroups, hipStream_t st)
-{
-    using namespace hssfsst;
-    const int G = ngroups;
-    if (G < 1 || G > kFusedMaxGroups) return 0;
-    constexpr int PLANES = tq_planes<KLO, KC>();
-    size_t lds = (kCanonLdsTabFloats + tq_ctl_floats() + static_cast<size_t>(WPB) * tq_wave_floats<KLO, KC>(PLANES)) * sizeof(float);
-    if (lds > static_cast<size_t>(kMaxLdsBytes)) return 0;
-    if (lds < 84 * 1024) lds = 84 * 1024;                // (one block per CU whatever its size: the teams count on it)
-    auto kern = fsst_teamq_kernel<KLO, KC, WPB, DEPTH>;
-    static std::atomic<unsigned long long> lds_ok{0};
-    if (int rc = allow_full_lds(kern, pl->device, lds_ok)) return rc;
-    if (pl->team16_cus == 0) {
-        int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * WPB, lds));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pl->device));
-        pl->team16_cus = (per_cu >= 1 && cus >= 1) ? cus : -1;
-    }
-    if (pl->team16_cus < 1) return 0;
-    // team size: the smallest power of two whose waves take a signal's groups in about half a round (16 T >= 2 G); HSSFSST_TEAM=n overrides
-    const int team_env = debug_switches().team;
-    int T = 1;
-    while ((WPB / 2) * T < G) T *= 2;
-    if (team_env > 0) { T = 1; while (2 * T <= team_env) T *= 2; }
-    if (T > pl->team16_cus || T > 256) return 0;
-    const int grid = (pl->team16_cus / T) * T;
-    const int nteams = grid / T;
-    if ((batch + nteams - 1) / nteams > 65535) return 0; // (16 bits of the signal ordinal in the mailbox tags)
-    if (cp.xstride < 1 || cp.xstride > 0x7fffffffLL || batch > 0x7fffffffLL) return 0;      // (the kernel's 32-bit signal index and stride)
-    // slots: a team's waves hold at most 6 tickets each (two held groups, one in its plane, transformed, landed, drawn): `lead` signals in
-    // flight; a slot is reused 2 lead + 2 signals later at the earliest
-    const int inflight = T * WPB * 6;
-    const int lead = (inflight + G - 1) / G + 1;
-    int slots = 8;
-    while (slots < 2 * lead + 2) slots *= 2;
-    const int slot_words = kTqGroupWords * G + 8;
-    const size_t words = static_cast<size_t>(nteams) * slots * slot_words;
-    if (slots > 4096 || words * 8 > (static_cast<size_t>(64) << 20)) return 0;
-    int rc;
-    if ((rc = ensure_status(pl)) != 0) return rc;
-    if (words > pl->mailq_cap) {
-        if ((rc = grow(reinterpret_cast<void**>(&pl->d_mailq), &pl->mailq_cap, words, sizeof(unsigned long long))) != 0) return rc;
-        HIP_TRY(hipMemsetAsync(pl->d_mailq, 0, pl->mailq_cap * sizeof(unsigned long long), st));
-        pl->teamq_seq = 0;
-    }
-    if (++pl->teamq_seq > 0xffffu) {                     // tags would repeat: start over from clean mailboxes
-        HIP_TRY(hipMemsetAsync(pl->d_mailq, 0, pl->mailq_cap * sizeof(unsigned long long), st));
-        pl->teamq_seq = 1;
-    }
-    if (nteams > kTqMaxTeams) return 0;
-    if (pl->tickets_cap == 0) {
-        if ((rc = grow(reinterpret_cast<void**>(&pl->d_tickets), &pl->tickets_cap, static_cast<size_t>(2 * kTqMaxTeams) * kTqTicketStride, sizeof(unsigned))) != 0) return rc;
-        HIP_TRY(hipMemsetAsync(pl->d_tickets, 0, pl->tickets_cap * sizeof(unsigned), st));
-        pl->tick_par = 0;
-    }
-    TeamqParams tp{};
-    tp.x = cp.x; tp.out = cp.out; tp.atab = pl->d_atab16; tp.wtab = cp.wtab; tp.twtab = cp.twtab;
-    tp.mail = pl->d_mailq; tp.tickets = pl->d_tickets; tp.r2scale_s = pl->canon_r2s; tp.inv_c = pl->canon_inv_c;
-    tp.n = cp.n; tp.nsig = cp.nsig; tp.col0 = cp.col0; tp.ncols = cp.ncols; tp.xstride = cp.xstride;
-    tp.team = T; tp.slots = slots; tp.slot_words = slot_words; tp.seq = pl->teamq_seq;
-    tp.tick_par = pl->tick_par; pl->tick_par ^= 1;
-    tp.g_magic = static_cast<unsigned>((0x100000000ULL / static_cast<unsigned long long>(G)) + 1ULL);
-    {   // the two float64 divisions of stats_finish (correctly rounded here as there: the same bits)
-        const double total = static_cast<double>(KC) * static_cast<double>(cp.ncols);
-        tp.inv_total = 1.0 / total; tp.inv_total1 = 1.0 / (total - 1.0);
-    }
-    const unsigned spin_us = debug_switches().team_spin_us;
-    tp.spin_ticks = (spin_us < 10u ? 10u : spin_us > 10000000u ? 10000000u : spin_us) * 100u;
-    if ((rc = ensure_team_words(pl, st)) != 0) return rc;
-    if (++pl->team_launch == 0u) pl->team_launch = 1u;
-    tp.abort_word = pl->d_arrive + 1; tp.fallbacks = pl->d_fallback; tp.launch = pl->team_launch;
-    if (debug_switches().team_force_fallback) {          // tests: every team launch finds itself given up
-        HIP_TRY(hipMemcpyAsync(pl->d_arrive + 1, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(pl->d_fallback, &pl->team_launch, sizeof(unsigned), hipMemcpyHostToDevice, st));
-    }
-    tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
-    pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
-    name_kernel(pl, WPB, grid, "fsst_teamq_kernel<%d, %d, %d, %d> teams of %d", KLO, KC, WPB, DEPTH, T);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, tp);
     HIP_TRY(hipGetLastError());
     return 1;
@@ -871,10 +784,7 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
         if (!no_team && canon16) {
-            if (debug_switches().team_static)
-                rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
-            else
-                rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_teamq<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
+            rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
                 // them apart: fsst_team16.hpp "Progress"): the same exec is queued behind it, every kernel of it gated on the
@@ -1006,40 +916,6 @@ int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nw
 #endif
 
 int hssfsst_version(void) { return HSSFSST_VERSION; }
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_BLKPROBE)
-int hssfsst_dev_t16_blk(unsigned* out)
-{
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_blk), sizeof(unsigned) * 256 * 16 * 8) == hipSuccess ? 0 : -2;
-}
-#endif
-#ifdef HSS_TQ_BLKPROBE       // development only (tools/blk_probe.py)
-int hssfsst_dev_t16_blk(unsigned* out)
-{
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_tq_blk), sizeof(unsigned) * 256 * 16 * 8) == hipSuccess ? 0 : -2;
-}
-#endif
-#ifdef HSS_T16_TLPROBE       // development only (tools/timeline.py)
-int hssfsst_dev_t16_tl(unsigned* out, int clear)
-{
-    constexpr size_t N = 16 * 16 * hssfsst::kTlCap * 2;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_tl), sizeof(unsigned) * N) != hipSuccess) return -2;
-    if (clear) { static unsigned z[N]; if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_tl), z, sizeof(z)) != hipSuccess) return -3; }
-    return 0;
-}
-#endif
-#if defined(HSS_T16_XCCPROBE) || defined(HSS_T16_MISSPROBE) || defined(HSS_T16_BLKPROBE)      // development only (tools/xcc_speed.py): out[256 * 4 + 8]
-int hssfsst_dev_t16_xcc(unsigned long long* out, int clear)
-{
-    constexpr size_t N = 256 * 4 + 8;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_xcc), sizeof(unsigned long long) * N) != hipSuccess) return -2;
-    if (clear) { static unsigned long long z[N]; if (hipMemcpyToSymbol(HIP_SYMBOL(hssfsst::g_t16_xcc), z, sizeof(z)) != hipSuccess) return -3; }
-    return 0;
-}
-#endif
 const char* hssfsst_last_error(void) { return g_err; }
 
 int hssfsst_device_count(void)
@@ -1362,8 +1238,6 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->h_status) (void)hipHostFree(const_cast<unsigned*>(p->h_status));
     if (p->d_mail) (void)hipFree(p->d_mail);
-    if (p->d_mailq) (void)hipFree(p->d_mailq);
-    if (p->d_tickets) (void)hipFree(p->d_tickets);
     if (p->d_arrive) (void)hipFree(p->d_arrive);
     if (p->h_fallback) (void)hipHostFree(const_cast<unsigned*>(p->h_fallback));
     if (p->d_stats) (void)hipFree(p->d_stats);
@@ -1371,6 +1245,7 @@ int hssfsst_plan_destroy(hssfsst_plan* p)
     if (p->d_ostage) (void)hipFree(p->d_ostage);
     if (p->h_xpin) (void)hipHostFree(p->h_xpin);
     if (p->h_opin) (void)hipHostFree(p->h_opin);
+    for (auto& b : p->pin_pool) if (b.h) (void)hipHostFree(b.h);
     if (p->d_starts) (void)hipFree(p->d_starts);
     if (p->d_frames) (void)hipFree(p->d_frames);
     for (auto& ev : p->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1411,6 +1286,7 @@ struct RcclApi {
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
     bool tried = false;
+    std::string why;                                     // why RCCL is not available (dlerror() answers once: kept)
 };
 RcclApi& rccl_api()
 {
@@ -1422,7 +1298,10 @@ RcclApi& rccl_api()
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
+            const char* e = dlerror();
+            if (e && api.why.empty()) api.why = e;
         }
+        if (api.handle) api.why = "symbol ncclAllGather missing";
         if (api.handle) {
             api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(api.handle, "ncclAllGather"));
             api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(api.handle, "ncclGetErrorString"));
@@ -1437,7 +1316,7 @@ int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void*
     if (!sendbuf || !recvbuf || !nccl_comm || count < 0 || timeout_ms < 0) return fail(HSSFSST_EINVAL, "allgather: bad argument");
     if (count == 0) return 0;
     RcclApi& api = rccl_api();
-    if (!api.all_gather) return fail(HSSFSST_EUNSUPPORTED, "allgather: RCCL (librccl.so.1: ncclAllGather) is not available: %s", api.handle ? "symbol missing" : dlerror());
+    if (!api.all_gather) return fail(HSSFSST_EUNSUPPORTED, "allgather: RCCL (librccl.so.1: ncclAllGather) is not available: %s", api.why.empty() ? "dlopen failed" : api.why.c_str());
     hipStream_t st = static_cast<hipStream_t>(stream);
     constexpr int kNcclFloat32 = 7;                      // ncclFloat (rccl.h)
     const int rc = api.all_gather(sendbuf, recvbuf, static_cast<size_t>(count), kNcclFloat32, nccl_comm, st);
@@ -1454,7 +1333,7 @@ int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void*
         e = hipSuccess;
         if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) {
             (void)hipEventDestroy(ev);
-            return fail(HSSFSST_EHIP, "allgather: the collective did not complete within %d ms (a rank is missing?)", timeout_ms);
+            return fail(HSSFSST_EHIP, "allgather: the collective did not complete within %d ms (a rank is missing?); it is still enqueued on the stream and owns both buffers", timeout_ms);
         }
         std::this_thread::yield();
     }
@@ -1553,8 +1432,10 @@ int hssfsst_exec_cols(hssfsst_plan* p, const float* x, int64_t batch, int n, int
 // buffer (fsst_gather_frames_kernel: 8 kB read + 8 kB written per frame, against 360 kB of output) and then takes the
 // same kernels as a dense batch: the transform kernels sit at the 128-VGPR limit of their occupancy and a second
 // addressing mode in them cost spilled registers.
+// (pin_d != nullptr: `out` is a pinned buffer of the plan's pool and pin_d its device alias -- hssfsst_exec_pinned: the kernels store the
+//  features there and nothing is copied; returns 1 when this exec is not one the kernels can write straight to host memory)
 static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int64_t x_stride, const long long* d_starts,
-                     size_t x_len, int col0, int ncols, int x_on_device, float* out, int out_on_device, void* stream)
+                     size_t x_len, int col0, int ncols, int x_on_device, float* out, int out_on_device, void* stream, float* pin_d = nullptr)
 {
     if (!p || !x || !out || batch < 0 || n < 1 || col0 < 0 || ncols < 1 || col0 > n - ncols || x_stride < 1)
         return fail(HSSFSST_EINVAL, "exec: bad argument (batch=%lld n=%d stride=%lld col0=%d ncols=%d)",
@@ -1591,8 +1472,12 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     // that the kernels read in place, and where the output is written exactly once (every mode but a STACK whose z-score is a
     // second pass over the features) the kernels store it into a pinned buffer too -- the mechanism of hssfsst_stream_step.
     const bool tiny_in = !x_on_device && nx <= (static_cast<size_t>(1) << 16);
+    // (STACK: only where the team kernel will take the exec -- its features are written once; a z-score that is a second pass would
+    //  read and rewrite them in place over PCIe: signals of more than 128 groups keep the device staging buffer + one copy)
     const bool tiny_out = tiny_in && !out_on_device && no <= (static_cast<size_t>(1) << 21) &&
-                          (p->mode != HSSFSST_MODE_STACK || (plan_is_canon(p) && (col0 & 15) == 0 && !debug_switches().no_team));
+                          (p->mode != HSSFSST_MODE_STACK || (plan_is_canon(p) && (col0 & 15) == 0 && !debug_switches().no_team &&
+                                                             p->zpath_pref != HSSFSST_ZPATH_ONE_CU && p->zpath_pref != HSSFSST_ZPATH_TWO_LAUNCH &&
+                                                             (ncols + 15) / 16 <= hssfsst::kFusedMaxGroups));
     auto pin = [&](float** h, float** d, size_t* cap, size_t need) -> int {
         if (*cap >= need) return 0;
         if (*h) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipHostFree(*h)); *h = nullptr; *d = nullptr; *cap = 0; }
@@ -1625,10 +1510,14 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         dx = p->d_frames;
         x_stride = n;
     }
+    if (pin_d && !tiny_out) return 1;                    // (not an exec whose features are written once: the caller takes the copying call)
     p->defer_fallback = false;
     if (tiny_out) {
-        if ((rc = pin(&p->h_opin, &p->d_opin, &p->opin_cap, no)) != 0) return rc;
-        dout = p->d_opin;
+        if (pin_d) dout = pin_d;
+        else {
+            if ((rc = pin(&p->h_opin, &p->d_opin, &p->opin_cap, no)) != 0) return rc;
+            dout = p->d_opin;
+        }
         p->defer_fallback = p->zpath_pref != HSSFSST_ZPATH_ONE_CU && !d_starts;
         p->deferred_launch = 0u;
     } else if (!out_on_device) {
@@ -1807,13 +1696,13 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             if (gu != 0u && (df <= dl ? (gu >= df && gu <= dl) : (gu >= df || gu <= dl))) {
                 const int keep = p->zpath_pref;
                 p->zpath_pref = HSSFSST_ZPATH_ONE_CU;
-                rc = exec_impl(p, x, batch, n, x_stride, d_starts, x_len, col0, ncols, x_on_device, out, out_on_device, stream);
+                rc = exec_impl(p, x, batch, n, x_stride, d_starts, x_len, col0, ncols, x_on_device, out, out_on_device, stream);      // (copies into `out`: a pool buffer is host memory too)
                 p->zpath_pref = keep;
                 return rc;
             }
         }
         if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;
-        std::memcpy(out, p->h_opin, no * sizeof(float));
+        if (!pin_d) std::memcpy(out, p->h_opin, no * sizeof(float));
     } else if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1828,6 +1717,47 @@ int hssfsst_exec_frames(hssfsst_plan* p, const float* x, int64_t batch, int n, i
                         int x_on_device, float* out, int out_on_device, void* stream)
 {
     return exec_impl(p, x, batch, n, x_stride, nullptr, 0, col0, ncols, x_on_device, out, out_on_device, stream);
+}
+
+// The dataset loop's call without the copy into the caller's tensor: the kernels store the features into a pinned, device-mapped buffer
+// of the plan's pool and the caller is LENT that buffer (hssfsst.h).
+constexpr size_t kPinPoolMax = 64;
+int hssfsst_exec_pinned(hssfsst_plan* p, const float* x, int n, float** out)
+{
+    if (!p || !x || !out || n < 1) return fail(HSSFSST_EINVAL, "exec_pinned: bad argument");
+    *out = nullptr;
+    if (p->K == 0) return 1;
+    DEVICE_SCOPE(p->device);
+    const size_t no = static_cast<size_t>(n) * out_floats_per_sample(p);
+    hssfsst_plan::PinBuf* b = nullptr;
+    for (auto& c : p->pin_pool) if (!c.used && c.cap >= no) { b = &c; break; }
+    if (!b) {
+        for (auto& c : p->pin_pool) if (!c.used) { b = &c; break; }       // (a free one that is too small is replaced)
+        if (!b) {
+            if (p->pin_pool.size() >= kPinPoolMax) return 1;               // every buffer is still in the caller's hands: take the copying call
+            p->pin_pool.push_back({nullptr, nullptr, 0, false});
+            b = &p->pin_pool.back();
+        }
+        if (b->h) { HIP_TRY(hipHostFree(b->h)); b->h = nullptr; b->d = nullptr; b->cap = 0; }
+        size_t c = 1 << 12;
+        while (c < no) c *= 2;
+        void* hp = nullptr; void* dp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, c * sizeof(float), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        b->h = static_cast<float*>(hp); b->d = static_cast<float*>(dp); b->cap = c;
+    }
+    const int rc = exec_impl(p, x, 1, n, static_cast<int64_t>(n), nullptr, 0, 0, n, 0, b->h, 0, nullptr, b->d);
+    if (rc != 0) return rc;
+    b->used = true;
+    *out = b->h;
+    return 0;
+}
+
+int hssfsst_pinned_release(hssfsst_plan* p, float* buf)
+{
+    if (!p || !buf) return fail(HSSFSST_EINVAL, "pinned_release: bad argument");
+    for (auto& c : p->pin_pool) if (c.h == buf) { c.used = false; return 0; }
+    return fail(HSSFSST_EINVAL, "pinned_release: not a buffer of this plan's pool");
 }
 
 int hssfsst_exec_list(hssfsst_plan* p, const float* x, int64_t x_len, const int64_t* starts, int starts_on_device,

@@ -10,6 +10,7 @@ There is no CPU implementation here: without the HIP library or a GPU every call
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 from typing import Optional
 
@@ -18,6 +19,15 @@ import numpy.typing as npt
 import torch
 
 from .. import _lib
+
+
+def _release_pinned(plan, addr: int) -> None:
+    """Finalizer of a tensor that borrowed a pinned pool buffer (holds the plan alive until the last such tensor is gone)."""
+    try:
+        if plan.handle and plan.handle.value and plan.pid == os.getpid():
+            plan._L.hssfsst_pinned_release(plan.handle, ctypes.c_void_p(addr))
+    except Exception:
+        pass
 
 
 class _Plan:
@@ -203,9 +213,24 @@ class FSST:
             plan = self._plan(self._device_index(x))
             n, K, m = x.numel(), plan.K, plan.mode
             if K > 0:
+                L = _lib.lib()
+                # the kernels store the features into a pinned buffer of the plan's pool and the returned tensor IS that buffer (no 352 kB
+                # copy): it goes back to the pool when the tensor dies; a caller that keeps every result finds the pool lent out after 64
+                # frames and gets freshly allocated tensors filled by a copy, as before (hssfsst.h: hssfsst_exec_pinned)
+                ptr = ctypes.c_void_p()
+                rc = L.hssfsst_exec_pinned(plan.handle, x.data_ptr(), n, ctypes.byref(ptr))
+                if rc == 0:
+                    nfl = n * plan.ofps
+                    buf = (ctypes.c_float * nfl).from_address(ptr.value)
+                    weakref.finalize(buf, _release_pinned, plan, ptr.value)
+                    if m == _lib.MODE_RAW:
+                        return torch.frombuffer(buf, dtype=torch.complex64).view(K, n)
+                    return torch.frombuffer(buf, dtype=torch.float32).view(n, K if m == _lib.MODE_ABS else 2 * K)
+                if rc < 0:
+                    _lib.check(rc, "hssfsst_exec_pinned")
                 out = (torch.empty((K, n), dtype=torch.complex64) if m == _lib.MODE_RAW
                        else torch.empty((n, K if m == _lib.MODE_ABS else 2 * K), dtype=torch.float32))
-                _lib.check(_lib.lib().hssfsst_exec_frames(plan.handle, x.data_ptr(), 1, n, n, 0, n, 0, out.data_ptr(), 0, None),
+                _lib.check(L.hssfsst_exec_frames(plan.handle, x.data_ptr(), 1, n, n, 0, n, 0, out.data_ptr(), 0, None),
                            "hssfsst_exec_frames")
                 return out
         x = self._as_f32(x)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 206
+#define HSSFSST_VERSION 207
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -90,6 +90,17 @@ int hssfsst_exec_cols(hssfsst_plan* plan, const float* x, int64_t batch, int n, 
 int hssfsst_exec_frames(hssfsst_plan* plan, const float* x, int64_t batch, int n, int64_t x_stride, int col0, int ncols,
                         int x_on_device, float* out, int out_on_device, void* stream);
 
+/* The reference's dataset loop calls the transform once per 2000-sample CPU frame (hss/datasets/heart_sounds.py:166-168,199-201).
+ * hssfsst_exec_pinned is hssfsst_exec for ONE host signal of n samples whose result is not copied: the kernels store the features
+ * straight into a pinned, device-mapped buffer of the plan's pool (at most 64 buffers) and *out is LENT that buffer -- n x
+ * floats-per-sample floats in the mode's layout, valid until hssfsst_pinned_release(plan, *out) or the plan's destruction.
+ * Returns 0; 1 (no error, *out = NULL) when every pool buffer is still lent out or the exec is not one whose features are written
+ * exactly once (then call hssfsst_exec); < 0 on error.  The Python class hands the buffer out as the returned tensor's storage and
+ * releases it when that tensor dies; a caller that keeps every result (the in-memory dataset) falls back to the copying call
+ * after 64 frames. */
+int hssfsst_exec_pinned(hssfsst_plan* plan, const float* x, int n, float** out);
+int hssfsst_pinned_release(hssfsst_plan* plan, float* buf);
+
 /* The same transform for a LIST of frames of one buffer: signal b = x[starts[b] .. starts[b] + n), 0 <= starts[b] <=
  * x_len - n (checked when `starts` is host memory; a device array is trusted).  This is the batched form of the
  * dataset loop hss/datasets/heart_sounds.py:155-169 over MANY recordings: the recordings sit back to back in `x`
@@ -142,7 +153,9 @@ int hssfsst_plan_fallbacks(hssfsst_plan* plan);
  * sendbuf may be recvbuf + rank x count: in place).  comm: the caller's ncclComm_t (one process per GPU).  RCCL is loaded with
  * dlopen("librccl.so.1") on first use: the library does not link it, and a host without it gets HSSFSST_EUNSUPPORTED here only.
  * timeout_ms > 0: the call waits for the collective on `stream`, at most that long (HSSFSST_EHIP when exceeded: a peer is missing
- * -- every wait of this library is bounded); 0: returns after enqueueing. */
+ * -- every wait of this library is bounded; the collective is then STILL ENQUEUED on `stream` and still owns both buffers: the
+ * caller must not reuse or free them before the stream has drained or the communicator was aborted); 0: returns after enqueueing.
+ * The call uses the CURRENT HIP device of the calling thread (the communicator's), it does not switch devices. */
 int hssfsst_allgather(const float* sendbuf, float* recvbuf, int64_t count, void* nccl_comm, void* stream, int timeout_ms);
 
 /* Per-kernel HIP-event timing on the exec stream (bench.py's roofline leg).  While enabled, every

@@ -206,7 +206,7 @@ static int setup_init(fsst_setup* s, const double* w, int N, double fs)
  * allocator's lock, VERDICT r05 "weak" 4).  `col` is ONE output column (nf complex sums). */
 typedef struct { double* buf; double* xp; double* col; float* fre; float* fim; } fsst_ws;
 
-static void ws_free(fsst_ws* q) { free(q->buf); free(q->xp); free(q->col); free(q->fre); free(q->fim); }
+static void ws_free(fsst_ws* q) { free(q->buf); free(q->xp); free(q->col); free(q->fre); free(q->fim); q->buf = q->xp = q->col = NULL; q->fre = q->fim = NULL; }
 
 static int ws_init(fsst_ws* q, int N, int nx, size_t nfeat)
 {
@@ -374,8 +374,19 @@ int hss_oracle_features(const float* x, int64_t batch, int nx, double fs, const 
 #pragma omp parallel num_threads(nthreads)
 #endif
     {
-        fsst_ws q;
-        const int have = ws_init(&q, N, nx, nfeat ? nfeat : 1);
+        /* a thread keeps its scratch from call to call (the baseline is timed over many short calls: allocated per call, each thread's
+         * ~0.7 MB came from mmap and went back with munmap every time -- page faults under one mm lock again) */
+        static _Thread_local fsst_ws tls_ws;
+        static _Thread_local int tls_N = 0, tls_nx = 0;
+        static _Thread_local size_t tls_nfeat = 0;
+        int have = 0;
+        if (tls_N != N || tls_nx != nx || tls_nfeat != (nfeat ? nfeat : 1)) {
+            if (tls_N != 0) ws_free(&tls_ws);
+            tls_N = 0;
+            have = ws_init(&tls_ws, N, nx, nfeat ? nfeat : 1);
+            if (have == 0) { tls_N = N; tls_nx = nx; tls_nfeat = nfeat ? nfeat : 1; }
+        }
+        fsst_ws q = tls_ws;
         if (have != 0) {
 #ifdef _OPENMP
 #pragma omp atomic write
@@ -422,7 +433,6 @@ int hss_oracle_features(const float* x, int64_t batch, int nx, double fs, const 
                 }
             }
         }
-        if (have == 0) ws_free(&q);
     }
     setup_free(&su);
     return err;

@@ -274,3 +274,17 @@ def test_team_kernel_fixed_registers_are_nobodys_else(tmp_path):
     for i in names:
         blk = "\n".join(text[i:i + 60])
         assert re.search(r"\.amdhsa_next_free_vgpr 128\b", blk), blk[:400]
+
+
+def test_shipped_code_object_keeps_the_fixed_registers():
+    """the check of `test_team_kernel_fixed_registers_are_nobodys_else` on the SHIPPED library (the code object inside
+    libhssfsst.so, disassembled), plus: no AGPR, no call, 128 registers reserved.  __graft_entry__.build() runs the same check."""
+    import os
+    import pytest
+    from heart_sounds_segmentation_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    out = _lib.check_code_object()
+    assert out["kernels"] >= 2 and out["metadata_checked"] >= 2 and out["accessor_instructions"] >= 100, out
