@@ -131,6 +131,46 @@ def live_traffic(kernel_substr, batch, timeout_s=150, extra_env=None):
                    "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch"}
 
 
+def power_leg(run_steps, seconds=2.0):
+    """Shader clock and socket power while the workload runs back to back (rocm-smi, sampled from a thread; OUTSIDE the timed region): on
+    real data this kernel sits at the chip's power limit and the clock gives way (profiles/r06_team_waits.txt section 4) -- the number that
+    explains why the same sources give 165-175 us on different boxes.  None where rocm-smi is missing."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    samples, stop = [], [False]
+
+    def watch():
+        while not stop[0]:
+            try:
+                r = subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                sclk = re.search(r"sclk clock level.*\((\d+)Mhz\)", r)
+                pw = re.search(r"Power \(W\):\s*([\d.]+)", r)
+                if sclk and pw:
+                    samples.append((int(sclk.group(1)), float(pw.group(1))))
+            except Exception:
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run_steps(200)
+    stop[0] = True
+    th.join(timeout=10)
+    s = samples[1:] if len(samples) > 3 else samples            # (the first sample may still see the idle clock)
+    if not s:
+        return None
+    clk = sorted(v[0] for v in s)
+    pw = sorted(v[1] for v in s)
+    return {"sclk_mhz": clk[len(clk) // 2], "power_w": round(pw[len(pw) // 2], 1), "power_w_max": round(pw[-1], 1), "samples": len(s),
+            "how": f"rocm-smi --showclocks --showpower every ~50 ms over {seconds:.0f} s of the same steps queued back to back, after the timed region; medians"}
+
+
 def _cpu_leg(X, w, threads, budget_s):
     """Windows per second of the oracle on `threads` OpenMP threads over about `budget_s` seconds of work."""
     import oracle
@@ -595,6 +635,17 @@ def main():
                                     "how": "HIP events on the exec stream inside the timed region, one per steps_per_sample steps"} if seg_ms else None),
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
                 "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / HBM_PEAK_GBS, 5)}
+        if world == 1 and not args.no_extras:
+            def _steps(k):
+                for _ in range(k):
+                    tf.batch(X, out=out)
+                torch.cuda.synchronize()
+            pw = power_leg(_steps)
+            if pw:
+                roof["sclk_mhz"], roof["power_w"] = pw["sclk_mhz"], pw["power_w"]
+                roof["power"] = pw
+                roof["power_note"] = ("on real data the kernel runs at the chip's power limit (~1 400 W) and the shader clock gives way (~2.2 GHz of 2.4): "
+                                      "a window's ENERGY bounds this path before its bytes do (profiles/r06_team_waits.txt)")
         if prof and all(k in prof for k in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES")) and prof["SQ_WAVE_CYCLES"] > 0:
             # the bound that actually binds: issue slots.  A wave64 VALU instruction holds its SIMD for 4 clocks, a
             # v_mfma_f32_16x16x32_f16 for 16 (they do not overlap: profiles/r01_mfma_valu_overlap_ubench.txt); SQ_WAVE_CYCLES counts 4-clock

@@ -34,7 +34,7 @@
 #if !defined(HSS_DEV) && (defined(HSS_ABLATE) || defined(HSS_CANON_ABLATE) || defined(HSS_T16_ABLATE) || defined(HSS_FUSE_PROBE) || \
                           defined(HSS_STREAM_PROBE) || defined(HSS_CLOCKPROBE) || defined(HSS_CANON_PROBE) || defined(HSS_NO_TIES) || \
                           defined(HSS_NO_EXACT) || defined(HSS_T16_NO_LAGPRIO) || defined(HSS_DEV_ONLY128) || defined(HSS_TAIL_ENV) || \
-                          defined(HSS_LDS_PAD) || defined(HSS_WPB_CANON) || defined(HSS_NO_GATE) || defined(HSS_T16_PLANES))
+                          defined(HSS_LDS_PAD) || defined(HSS_WPB_CANON) || defined(HSS_NO_GATE) || defined(HSS_T16_PLANES) || defined(HSS_T16_BLKPROBE))
 #error "development hook without -DHSS_DEV: the shipped library carries none (tools/dev.sh builds development libraries)"
 #endif
 #include <hip/hip_runtime.h>

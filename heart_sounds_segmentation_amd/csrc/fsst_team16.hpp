@@ -68,10 +68,14 @@ namespace hssfsst {
 
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
+#ifdef HSS_T16_BLKPROBE      // development (tools/blk_probe.py): per wave of the LAST launch: waits, -, ticks waited, ticks resolving, resolves
+__device__ unsigned g_t16_blk[256 * 16 * 8];
+#endif
 constexpr int kT16PartFloats = 6;            // a group's statistics partial in the CU's LDS: S1re S2re S1im S2im p_re p_im
 constexpr int kT16BlockWords = 8;            // tagged 8-byte words per BLOCK of kStatBlock groups in the mailbox: the block's four
                                              // float64 sums (sum re, sum re^2, sum im, sum im^2), each as {high, low} half
 constexpr int kT16MaxBlocks = kFusedMaxGroups / kStatBlock;      // 32 blocks per signal
+constexpr int kT16SlotWords = kT16MaxBlocks * kT16BlockWords;          // a signal's mailbox slot
 constexpr int kT16MaxCpc = 8;                // groups of a signal per CU (two blocks)
 constexpr int kT16MaxSlots = 64;             // statistics slots per CU / mailbox slots per team (signal ordinal mod slots); 32 where the LDS is short
 constexpr int kT16StatFloats = 12;           // a signal's statistics in LDS: three float4 {mean, 1/std} pairs -- (re, re), (re, im), (im, im): the
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     const int G = (ncols + 15) >> 4;
     const int cg0 = p.col0 >> 4;                         // (the host sends only column ranges that start on a group boundary)
     const int smask = p.slots - 1;
-    constexpr int nwords = kT16MaxBlocks * kT16BlockWords;     // tagged words per signal in the mailbox
+    constexpr int nwords = kT16SlotWords;                      // tagged words per signal in the mailbox
     gu64* mail = (gu64*)(p.mail) + static_cast<size_t>(team) * static_cast<size_t>(p.slots) * nwords;
     const int nblocks = (G + kStatBlock - 1) / kStatBlock;
     const unsigned sig_bytes = static_cast<unsigned>(ncols) * (2 * K * 4);         // a signal's feature block (at most 128 groups: 32 bits)
@@ -302,6 +306,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     };
     auto draw = [&](int after_ko) { draw_ask(after_ko); draw_take(); };
 
+#ifdef HSS_T16_BLKPROBE
+    unsigned pb_miss = 0u, pb_blocked = 0u, pb_fin = 0u, pb_nfin = 0u;
+    const unsigned long long pb_c0 = __builtin_readcyclecounter(), pb_r0 = wall_clock64();
+#endif
     auto stats_ready = [&](int ko) -> bool {             // the CU already has this signal's statistics
         unsigned have = 0u;
         if (lane == 0) have = __hip_atomic_load(ready + (ko & smask), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -321,9 +329,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     // blk + 16 (its 16-byte pairs l and l + 64: the mailbox is laid out for exactly that), adds them in that order and runs
     // stats_finish: the instructions of stats_from_blocks() on the numbers of the two-launch path.
     // the claim is this wave's: look at the mailbox until both of the lane's blocks are there
-    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) {
-        // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
-        __builtin_amdgcn_s_setprio(3);
+    auto blocks_to_stats = [&](int ko, unsigned t0, int lane_r) __attribute__((always_inline)) -> float4 {
         const unsigned tag = (P()->seq << 16) | (static_cast<unsigned>(ko) & 0xffffu);
         const gu64* slot = mail + static_cast<size_t>(ko & smask) * nwords;
         const int blk0 = lane_r >> 2;
@@ -350,7 +356,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         if (blk0 < nblocks) acc += sb[0];
         if (blk0 + 16 < nblocks) acc += sb[1];
         static_assert(kT16MaxBlocks <= 32, "a lane sums at most two blocks");
-        const float4 r = stats_finish_lead(acc, P()->inv_total, P()->inv_total1, lane_r);
+        return stats_finish_lead(acc, P()->inv_total, P()->inv_total1, lane_r);
+    };
+    auto resolve_owned = [&](int ko, unsigned t0, int lane_r) __attribute__((always_inline)) {
+        // (fifteen siblings and, soon, other CUs wait for what this wave does now: it goes first on its SIMD)
+        __builtin_amdgcn_s_setprio(3);
+        float4 r;
+        r = blocks_to_stats(ko, t0, lane_r);
         if (lane == 0) {
             float4* f3 = fin + 3 * (ko & smask);
             f3[0] = make_float4(r.x, r.y, r.x, r.y);
@@ -371,12 +383,25 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
         const unsigned t0 = static_cast<unsigned>(wall_clock64());
+#ifdef HSS_T16_BLKPROBE
+        ++pb_miss;
+        struct Fin { unsigned& acc; unsigned t; __device__ ~Fin() { acc += static_cast<unsigned>(wall_clock64()) - t; } } fin_{pb_blocked, t0};
+#endif
 #if defined(HSS_T16_ABLATE) && HSS_T16_ABLATE == 3      // development: the resolver resolves, nobody else waits (results invalid)
         if (try_claim(ko)) resolve_owned(ko, t0, lane_r);
         return;
 #endif
         for (unsigned spins = 0;; ++spins) {
-            if ((spins & 15u) == 0u && try_claim(ko)) { resolve_owned(ko, t0, lane_r); return; }
+            if ((spins & 15u) == 0u && try_claim(ko)) {
+#ifdef HSS_T16_BLKPROBE
+                const unsigned tr = static_cast<unsigned>(wall_clock64());
+                resolve_owned(ko, t0, lane_r);
+                pb_fin += static_cast<unsigned>(wall_clock64()) - tr; ++pb_nfin;
+                return;
+#else
+                resolve_owned(ko, t0, lane_r); return;
+#endif
+            }
             if ((spins & 31u) == 31u && expired(t0)) { gave_up(); leave(); }
             if (is_dead()) leave();
             __builtin_amdgcn_s_sleep(4);
@@ -480,7 +505,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
         {   // a group of a signal the CU's ticket counter has left behind is what other waves will soon wait for: it goes first
             // (what the wave's own next ticket says about the counter -- a group time old, but no trip to LDS)
             const int lag = (d_valid ? ko_d : ko + 2) - ko;
-            if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower)
+            if (lag >= 2) __builtin_amdgcn_s_setprio(2); else if (lag == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);      // (3 / 2: slower; off: +2.8 %)
         }
 #endif
         f2* own_base = own_first + cur * (16 * C::LD);
@@ -696,6 +721,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(S, ko_hs[sl], g_hs[sl]); }
         });
     }
+#ifdef HSS_T16_BLKPROBE
+    if (lane == 0 && virt < 256) {
+        unsigned* e = g_t16_blk + (virt * 16 + wv) * 8;
+        e[0] = pb_miss; e[1] = 0u; e[2] = pb_blocked; e[3] = pb_fin; e[4] = pb_nfin;
+        e[5] = static_cast<unsigned>(__builtin_readcyclecounter() - pb_c0); e[6] = static_cast<unsigned>(wall_clock64() - pb_r0);
+    }
+#endif
 }
 
 }  // namespace hssfsst

@@ -591,7 +591,7 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     if (lead + 1 > PSLOTS) return 0;                     // (very short signals: more signals in flight per CU than its LDS keeps partials for)
     int rc;
     if ((rc = ensure_status(pl)) != 0) return rc;
-    const size_t words = static_cast<size_t>(nteams) * slots * kT16MaxBlocks * kT16BlockWords;
+    const size_t words = static_cast<size_t>(nteams) * slots * kT16SlotWords;
     if (words > pl->mail_cap) {
         if ((rc = grow(reinterpret_cast<void**>(&pl->d_mail), &pl->mail_cap, words, sizeof(unsigned long long))) != 0) return rc;
         HIP_TRY(hipMemsetAsync(pl->d_mail, 0, pl->mail_cap * sizeof(unsigned long long), st));
@@ -931,6 +931,13 @@ int hssfsst_dev_stream_probe(unsigned long long* out, int nwaves)      // out[nw
 #endif
 
 int hssfsst_version(void) { return HSSFSST_VERSION; }
+#ifdef HSS_T16_BLKPROBE      // development only (tools/blk_probe.py)
+int hssfsst_dev_t16_blk(unsigned* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hssfsst::g_t16_blk), sizeof(unsigned) * 256 * 16 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
 const char* hssfsst_last_error(void) { return g_err; }
 
 int hssfsst_device_count(void)

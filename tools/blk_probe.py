@@ -26,4 +26,4 @@ for r in range(3):
     miss, blocked, fin, nfin = a[:, 0], a[:, 2] / 100.0, a[:, 3] / 100.0, a[:, 4]
     print(f"{os.path.basename(sys.argv[1])} {kind}: {e0.elapsed_time(e1) / K * 1e3:.1f} us per exec; last launch: misses {miss.sum() / 128000 * 100:.1f} % of the groups, "
           f"{blocked.sum() / max(miss.sum(), 1):.2f} us waited per miss = {blocked.mean():.2f} us per wave (p90 {np.percentile(blocked, 90):.2f}, max {blocked.max():.2f}); "
-          f"finishers wait {fin.sum() / max(nfin.sum(), 1):.2f} us per signal = {fin.mean():.2f} us per wave; groups per wave min {a[:, 5].min():.0f} max {a[:, 5].max():.0f} sum {a[:, 5].sum():.0f}")
+          f"resolvers take {fin.sum() / max(nfin.sum(), 1):.2f} us per signal = {fin.mean():.2f} us per wave; shader clock {100.0 * a[:, 5].sum() / max(a[:, 6].sum(), 1):.0f} MHz (cycle counter / 100 MHz clock over the waves' lifetimes: mean {a[:, 6].mean() / 100:.1f} us)")
