@@ -88,6 +88,23 @@ def census_max_rel_err():
     return None
 
 
+def box_spread():
+    """The dominant kernel's spread over GPU leases of one source tree (profiles/rNN_box_spread.json: the newest round's committed
+    A/B baselines, one row per lease).  A run of this script sees ONE box; this says where it may sit among the others."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_box_spread.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            return {"per_exec_us": {"min": d["min"], "median": d["median"], "max": d["max"]}, "leases": d["leases"],
+                    "frac_of_peak": {"min": round(BYTES_PER_WINDOW * 1024 / (d["max"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "max": round(BYTES_PER_WINDOW * 1024 / (d["min"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "source": os.path.relpath(path, ROOT), "why": d.get("why")}
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
 def live_traffic(kernel_substr, batch, timeout_s=150, extra_env=None):
     """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two short child runs of this very script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no tracing, as MI355X_MICROARCH.md prescribes:
@@ -635,6 +652,8 @@ def main():
                                     "how": "HIP events on the exec stream inside the timed region, one per steps_per_sample steps"} if seg_ms else None),
                 # the whole path (every kernel of a step + gaps), the figure north_star's 40 % is about
                 "step_achieved": round(step_gbs, 2), "step_frac": round(step_gbs / HBM_PEAK_GBS, 5)}
+        if B == 1024 and "team16" in kname:
+            roof["box_spread"] = box_spread()
         if world == 1 and not args.no_extras:
             def _steps(k):
                 for _ in range(k):
