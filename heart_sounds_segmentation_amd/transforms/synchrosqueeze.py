@@ -10,7 +10,6 @@ There is no CPU implementation here: without the HIP library or a GPU every call
 from __future__ import annotations
 
 import ctypes
-import weakref
 import os
 from typing import Optional
 
@@ -22,12 +21,30 @@ from .. import _lib
 
 
 def _release_pinned(plan, addr: int) -> None:
-    """Finalizer of a tensor that borrowed a pinned pool buffer (holds the plan alive until the last such tensor is gone)."""
+    """A pinned pool buffer goes back to its plan (the borrower holds the plan alive until then)."""
     try:
         if plan.handle and plan.handle.value and plan.pid == os.getpid():
             plan._L.hssfsst_pinned_release(plan.handle, ctypes.c_void_p(addr))
     except Exception:
         pass
+
+
+_LENT_TYPES = {}
+
+
+def _lent_type(nfl: int):
+    """ctypes float array type over a LENT pinned pool buffer: the numpy array / tensor made from an instance keeps it alive, and when the last
+    view of the result is gone the instance's ``__del__`` hands the buffer back (``hssfsst_pinned_release``).  (A subclass with ``__del__``
+    + ``np.frombuffer`` + ``torch.from_numpy`` costs 1.4 us per call; ``weakref.finalize`` + ``torch.frombuffer`` + ``view`` cost 3.3.)"""
+    T = _LENT_TYPES.get(nfl)
+    if T is None:
+        class _Lent(ctypes.c_float * nfl):
+            _plan = None
+
+            def __del__(self):
+                _release_pinned(self._plan, ctypes.addressof(self))
+        T = _LENT_TYPES[nfl] = _Lent
+    return T
 
 
 class _Plan:
@@ -92,6 +109,7 @@ class FSST:
         self.dtype = dtype
         self.device = device
         self._plans = {}
+        self._cuda_seen = False
 
     # ------------------------------------------------------------------ plan / geometry
     def _mode(self) -> int:
@@ -128,6 +146,7 @@ class FSST:
     def __getstate__(self):          # plans hold device handles: never pickle them into workers
         st = self.__dict__.copy()
         st["_plans"] = {}
+        st["_cuda_seen"] = False
         return st
 
     def band(self):
@@ -208,24 +227,28 @@ class FSST:
         """
         # the dataset loop's call -- a CPU float32 (n,) / (n, 1) frame, once per 2000 samples (heart_sounds.py:166-168,199-201) --
         # goes straight to the C ABI: of a 0.057 ms call the generic path below spent 0.012 ms on conversions and checks
-        if (type(x) is torch.Tensor and x.dtype == torch.float32 and x.device.type == "cpu" and x.is_contiguous()
-                and not x.requires_grad and (x.ndim == 1 or (x.ndim == 2 and 1 in x.shape)) and x.numel() > 0):
-            plan = self._plan(self._device_index(x))
+        if (type(x) is torch.Tensor and x.dtype is torch.float32 and x.is_cpu and x.is_contiguous()
+                and not x.requires_grad and (x.dim() == 1 or (x.dim() == 2 and 1 in x.shape)) and x.numel() > 0):
+            if self.device is None and self._cuda_seen:  # (the checks of _device_index were made by an earlier call of this process)
+                _lib.guard_fork()
+                plan = self._plan(torch.cuda.current_device())
+            else:
+                plan = self._plan(self._device_index(x))
+                self._cuda_seen = True
             n, K, m = x.numel(), plan.K, plan.mode
             if K > 0:
                 L = _lib.lib()
                 # the kernels store the features into a pinned buffer of the plan's pool and the returned tensor IS that buffer (no 352 kB
-                # copy): it goes back to the pool when the tensor dies; a caller that keeps every result finds the pool lent out after 64
-                # frames and gets freshly allocated tensors filled by a copy, as before (hssfsst.h: hssfsst_exec_pinned)
+                # copy): it goes back to the pool when the last view of the result dies; a caller that keeps every result finds the pool lent
+                # out after 64 frames and gets freshly allocated tensors filled by a copy, as before (hssfsst.h: hssfsst_exec_pinned)
                 ptr = ctypes.c_void_p()
                 rc = L.hssfsst_exec_pinned(plan.handle, x.data_ptr(), n, ctypes.byref(ptr))
                 if rc == 0:
-                    nfl = n * plan.ofps
-                    buf = (ctypes.c_float * nfl).from_address(ptr.value)
-                    weakref.finalize(buf, _release_pinned, plan, ptr.value)
+                    buf = _lent_type(n * plan.ofps).from_address(ptr.value)
+                    buf._plan = plan
                     if m == _lib.MODE_RAW:
-                        return torch.frombuffer(buf, dtype=torch.complex64).view(K, n)
-                    return torch.frombuffer(buf, dtype=torch.float32).view(n, K if m == _lib.MODE_ABS else 2 * K)
+                        return torch.from_numpy(np.frombuffer(buf, dtype=np.complex64).reshape(K, n))
+                    return torch.from_numpy(np.frombuffer(buf, dtype=np.float32).reshape(n, K if m == _lib.MODE_ABS else 2 * K))
                 if rc < 0:
                     _lib.check(rc, "hssfsst_exec_pinned")
                 out = (torch.empty((K, n), dtype=torch.complex64) if m == _lib.MODE_RAW

@@ -18,6 +18,12 @@ plan = tf._plan(0)
 x = np.ascontiguousarray(fr.numpy().reshape(-1)); out = np.empty((2000, 44), np.float32)
 xp, op = ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data)
 print(f"hssfsst_exec host -> host (raw)    {t(lambda: L.hssfsst_exec(plan.handle, xp, 1, 2000, 0, op, 0, None)):.1f} us")
+pp = ctypes.c_void_p()
+def pinned():
+    rc = L.hssfsst_exec_pinned(plan.handle, xp, 2000, ctypes.byref(pp))
+    assert rc == 0
+    L.hssfsst_pinned_release(plan.handle, pp)
+print(f"hssfsst_exec_pinned + release (raw) {t(pinned):.1f} us")
 xd = torch.from_numpy(x).cuda(); od = torch.empty((1, 2000, 44), device='cuda')
 xdp, odp = ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(od.data_ptr())
 def dev():
