@@ -127,6 +127,10 @@ struct Team16Params {
     unsigned* abort_word; // a wait that ran out of time stores `launch` here; every wave then leaves the kernel
     unsigned* fallbacks;  // pinned host word: the same store, for the host's eyes
     unsigned launch;      // identity of this launch (never 0)
+    unsigned* done;       // host_done != nullptr: counter of the blocks whose waves have all stored their last feature (monotone over such launches) ...
+    unsigned done_base;   // ... its value before this launch ...
+    unsigned* host_done;  // ... and the pinned host word the LAST block stores `launch` to: a host that waits for this exec alone looks at that word
+                          //     instead of synchronising the stream (no end-of-kernel flush and completion signal in its way: 6 us of a 35 us call)
     double inv_total, inv_total1;   // 1 / (K ncols), 1 / (K ncols - 1): the two divisions of stats_finish, made once on the host
 };
 
@@ -720,6 +724,26 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
             constexpr int sl = decltype(S)::value;
             if (so == sl) { signal_statistics(ko_hs[sl]); emit_held(S, ko_hs[sl], g_hs[sl]); }
         });
+    }
+    // ---- a host that waits for this launch alone: a wave counts itself in (LDS) once its stores have left it; the block's last wave makes the
+    //      block's stores visible at system scope -- the features may lie in pinned host memory; one L2 write-back per block, not per wave --
+    //      and counts the block in; the grid's last block says so in pinned host memory.  (A launch that was given up never gets here: the
+    //      host sees the give-up word instead.)
+    if (P()->host_done != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        unsigned last = 0u;
+        if (lane == 0) last = __hip_atomic_fetch_add(next_q + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == WPB - 1 ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(last) != 0u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // (system scope)
+            if (lane == 0) {
+                const unsigned before = __hip_atomic_fetch_add(P()->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P()->done_base;
+                if (before + 1u == gridDim.x) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+                    __hip_atomic_store((gu32*)(P()->host_done), P()->launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
     }
 #ifdef HSS_T16_BLKPROBE
     if (lane == 0 && virt < 256) {

@@ -239,7 +239,9 @@ struct hssfsst_plan {
     volatile unsigned* h_status = nullptr;                   // ... and the same word in pinned host memory: read without a sync
     unsigned long long* d_mail = nullptr; size_t mail_cap = 0;   // team kernel: mailboxes [teams][slots][32 blocks][8] (8-byte words)
     unsigned team_seq = 0;                                   // launch sequence number (upper half of the mailbox tags)
-    unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word
+    unsigned* d_arrive = nullptr; unsigned arrive_total = 0; // team kernel: [0] arrival counter (and its value after the launches so far), [1] abort word, [2] blocks done
+    unsigned done_total = 0;                                 // ... [2]'s value after the flagged launches so far
+    bool flag_done = false; unsigned flag_launch = 0;        // exec_impl asks the next team launch to say in pinned host memory (h_fallback[2]) when its last wave is done; that launch
     unsigned team_launch = 0;                                // identity of the last team launch (never 0)
     volatile unsigned* h_fallback = nullptr; unsigned* d_fallback = nullptr;   // pinned host word: identity of the last team launch that gave up
     unsigned seen_fallback = 0; int fallbacks = 0;           // ... as last seen by the host, and how many distinct ones
@@ -524,13 +526,13 @@ int ensure_status(hssfsst_plan* pl)
 int ensure_team_words(hssfsst_plan* pl, hipStream_t st)
 {
     if (pl->d_arrive) return 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), 2 * sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 2 * sizeof(unsigned), st));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pl->d_arrive), 4 * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(pl->d_arrive, 0, 4 * sizeof(unsigned), st));
     pl->arrive_total = 0;
+    pl->done_total = 0;
     void* h = nullptr;
-    HIP_TRY(hipHostMalloc(&h, 2 * sizeof(unsigned), hipHostMallocMapped));
-    static_cast<volatile unsigned*>(h)[0] = 0u;
-    static_cast<volatile unsigned*>(h)[1] = 0u;
+    HIP_TRY(hipHostMalloc(&h, 4 * sizeof(unsigned), hipHostMallocMapped));
+    for (int i = 0; i < 4; ++i) static_cast<volatile unsigned*>(h)[i] = 0u;
     void* d = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
     pl->h_fallback = static_cast<volatile unsigned*>(h);
@@ -622,6 +624,12 @@ int launch_team16(hssfsst_plan* pl, const hssfsst::Core128Params& cp, int64_t ba
     }
     tp.arrive = pl->d_arrive; tp.arrive_base = pl->arrive_total;
     pl->arrive_total += static_cast<unsigned>(grid);     // (a plan is single-stream: every block of the earlier launches has arrived)
+    pl->flag_launch = 0u;
+    if (pl->flag_done && !force_fallback) {              // (hssfsst_exec_pinned & co: the host waits for this exec alone)
+        tp.done = pl->d_arrive + 2; tp.done_base = pl->done_total; tp.host_done = pl->d_fallback + 2;
+        pl->done_total += static_cast<unsigned>(grid);
+        pl->flag_launch = pl->team_launch;
+    }
     name_kernel(pl, WPB, grid, "fsst_team16_kernel<%d, %d, %d, %d> teams of %d", KLO, KC, WPB, DEPTH, T);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(64 * WPB), lds, st, tp);
     HIP_TRY(hipGetLastError());
@@ -1576,6 +1584,10 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
     }
     const int64_t chunk = (batch + nchunks - 1) / nchunks;
     const bool piped = nchunks > 1;
+    // a host-output exec of one team launch: the launch's last wave says "done" in pinned host memory and this call waits for that word
+    // instead of synchronising the stream (below)
+    p->flag_done = tiny_out && p->defer_fallback && !p->timing && nchunks == 1;
+    p->flag_launch = 0u;
     if (piped) {
         if (!p->aux) HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
         while (static_cast<int64_t>(p->sync_ev.size()) < nchunks + 1) {
@@ -1708,7 +1720,32 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
         }
     }
     if (tiny_out) {
-        HIP_TRY(hipStreamSynchronize(st));
+        // The team launch of this exec, if it was asked to (flag_done): its last wave stores the launch's identity to h_fallback[2] behind a
+        // system-scope release of every wave's stores -- the features are in pinned host memory by then.  Waiting for that word instead of
+        // the stream's completion signal spares the end-of-kernel cache flush and the signal's way to the host: 6 us of a 35 us call
+        // (tools/sync_latency.hip).  A launch that gave itself up never stores it: the give-up word ends the wait, as does a bound.
+        bool seen = false;
+        const unsigned fl = (p->flag_done && p->flag_launch != 0u && p->flag_launch == p->deferred_launch && p->deferred_first == p->deferred_launch)
+                            ? p->flag_launch : 0u;
+        p->flag_done = false;
+        p->flag_launch = 0u;
+        if (fl != 0u && p->h_fallback) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; ++it) {
+                if (p->h_fallback[2] == fl) { seen = true; break; }
+                if (p->h_fallback[0] == fl) break;                                   // given up: the usual way below
+                if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+                __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (fl != 0u) {                               // (the blocks of a given-up launch did not all count themselves in: start the count over)
+                HIP_TRY(hipMemsetAsync(p->d_arrive + 2, 0, sizeof(unsigned), st));
+                p->done_total = 0;
+            }
+        }
         p->defer_fallback = false;
         if (p->deferred_launch != 0u) {
             // no gated kernels were queued behind this exec's team launch: if that launch gave itself up (pinned word, written with
@@ -1726,7 +1763,13 @@ static int exec_impl(hssfsst_plan* p, const float* x, int64_t batch, int n, int6
                 return rc;
             }
         }
-        if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;
+        if (seen) {                                       // (the status word is pinned host memory too: written before the wave that wrote it counted itself in)
+            if (p->h_status && *p->h_status != 0u) {
+                const unsigned code = *p->h_status;
+                *p->h_status = 0u;
+                return fail(HSSFSST_EHIP, "fused z-score: a wait inside the kernel gave up (code %u); results of that exec are invalid", code);
+            }
+        } else if (p->d_status && (rc = hssfsst_plan_check(p)) != 0) return rc;
         if (!pin_d) std::memcpy(out, p->h_opin, no * sizeof(float));
     } else if (!out_on_device) {
         HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, st));

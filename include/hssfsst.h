@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HSSFSST_VERSION 207
+#define HSSFSST_VERSION 208
 
 /* status codes */
 #define HSSFSST_OK 0
@@ -70,7 +70,10 @@ int hssfsst_plan_info(const hssfsst_plan* plan, int* nwin, int* nf, int* klo, in
  * `batch` independent signals of `n` samples each (x: float32 [batch][n], contiguous).
  * out: float32, batch * n * out_floats_per_sample elements, laid out per mode (see HSSFSST_MODE_*),
  * each signal's block contiguous.  x_on_device / out_on_device: 1 = device pointer on the plan's
- * device, 0 = host pointer.  stream: hipStream_t or NULL. */
+ * device, 0 = host pointer.  stream: hipStream_t or NULL.
+ * A call with a host `out` returns when the features are in `out`.  For small execs (the dataset loop's one frame per call) it learns that
+ * from a word the kernel's last block stores to pinned host memory behind a system-scope release of all stores, not from the stream:
+ * `stream` may still be retiring that launch for a few microseconds after the return (later work on it queues behind, as always). */
 int hssfsst_exec(hssfsst_plan* plan, const float* x, int64_t batch, int n, int x_on_device,
                  float* out, int out_on_device, void* stream);
 

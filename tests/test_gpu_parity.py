@@ -888,6 +888,34 @@ def test_pinned_result_buffers_are_lent_and_returned():
     assert a1.shape == (2000, 22) and torch.equal(a1, FSST(1000, KAISER, truncate_freq=BAND, abs=True).batch(X[1:2].cuda())[0].cpu())
 
 
+def test_one_window_calls_return_only_finished_results():
+    """A host-output exec of one team launch does not synchronise the stream: it waits for a word the launch's last block stores to pinned
+    host memory behind a system-scope release of every block's stores (hssfsst.hip exec_impl, fsst_team16.hpp).  4000 back-to-back calls
+    on changing frames -- lent buffers (a few kept alive, so the pool rotates) and the copying call alike -- must each equal the batched
+    device path bit for bit: a result handed out before its features had landed would hold an older call's."""
+    tf = FSST(1000, KAISER, truncate_freq=BAND, stack=True)
+    B = 96
+    X = torch.from_numpy(np.concatenate([synth.pcg_windows(B // 2, 2000, seed=5), synth.noise_windows(B // 2, 2000, seed=6)]).astype(np.float32))
+    want = tf.batch(X.cuda()).cpu()
+    frames = [X[i].reshape(2000, 1).contiguous() for i in range(B)]
+    order = np.random.default_rng(3).integers(0, B, size=4000)
+    held, bad = [], 0
+    for k, i in enumerate(order):
+        y = tf(frames[int(i)])
+        bad += 0 if torch.equal(y, want[int(i)]) else 1
+        held.append(y)
+        if len(held) > 5:
+            held.pop(0)
+    assert bad == 0
+    L, plan = _lib.lib(), tf._plan(0)
+    out = np.empty((2000, 44), np.float32)
+    for i in order[:500]:                                # the copying call (hssfsst_exec on host buffers) takes the same wait
+        x = np.ascontiguousarray(X[int(i)].numpy())
+        assert L.hssfsst_exec(plan.handle, x.ctypes.data, 1, 2000, 0, out.ctypes.data, 0, None) == 0
+        assert np.array_equal(out, want[int(i)].numpy())
+    assert L.hssfsst_plan_fallbacks(plan.handle) == 0
+
+
 def test_corpus_builder_and_end_to_end(oracle_mod):
     """the batched dataset builder yields what the reference's loop would
     (33 frames per 35 000-sample recording, (2000, 44) float32 + (2000,) labels shifted to 0..3,
