@@ -168,6 +168,9 @@ template <int KLO, int KC, int WPB, int DEPTH>
 // (amdgpu_num_vgpr(52): the attribute counts in register PAIRS on this target -- 104 allocatable registers; v104 .. v127 are the held images')
 __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(52))) void fsst_team16_kernel(Team16Params p)
 {
+#ifdef HSS_T16_BLKPROBE
+    const unsigned pb_entry = static_cast<unsigned>(wall_clock64());       // (absolute: the 100 MHz counter is the chip's)
+#endif
     using C = CanonCfg<KLO, KC>;
     static_assert(WPB % 4 == 0 && DEPTH >= 1 && DEPTH <= 2, "whole waves per SIMD; two held groups (v104 .. v127)");
     static_assert(DEPTH == 2, "the kernel is compiled for 104 allocatable registers + 24 fixed ones");
@@ -195,15 +198,16 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     int* flag = reinterpret_cast<int*>(own_first + PLANES * 16 * C::LD);
     int* tq = flag + kCanonFlagWords;
 
+    // Block identity = ARRIVAL number ("Giving up" above).  Asked for FIRST: the trip to the counter (1.5-2 us) runs beside the table's loads, not behind them
+    unsigned arrived = 0u;
+    if (threadIdx.x == 64) arrived = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base;
     for (int i = threadIdx.x; i < ATAB; i += 64 * WPB) atab[i] = p.atab[i];
     if (lane < kCanonFlagWords) flag[lane] = 0;
     if (lane < kCanonTieWords) tq[lane] = 0;
     if (threadIdx.x < 16 && threadIdx.x != 2) next_q[threadIdx.x] = 0;       // ([2]: the identity, written below)
     for (int i = threadIdx.x; i < 2 * MS; i += 64 * WPB) ready[i] = 0u;       // ready[], claim[]
     if (threadIdx.x < 2 * PSLOTS) pcnt_lds[threadIdx.x] = 0;
-    // Block identity = ARRIVAL number ("Giving up" above)
-    if (threadIdx.x == 64)
-        next_q[2] = static_cast<int>(__hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.arrive_base);
+    if (threadIdx.x == 64) next_q[2] = static_cast<int>(arrived);
     if (wv == 0) {
         unsigned cofs = 0u;                              // byte i: 16 x (number of imaginary column pairs of float4 lane + 64 i)
 #pragma unroll
@@ -247,7 +251,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     // an identity outside the grid = arrivals of two launches of one plan interleaved (a plan is single-stream: hssfsst.h):
     // give the launch up instead of indexing outside the mailboxes (the gated fallback computes the exec)
     if (static_cast<unsigned>(virt) >= gridDim.x) { gave_up(); return; }
-    if (aborted()) return;                               // (a block that starts after the launch was given up)
+    // (a block that starts after the launch was given up: the look at the abort word is ASKED here and looked at behind the first draw -- its trip
+    //  runs beside the first tile's samples', not in front of them; asked with the arrival's trip, its answer handed on through LDS: slower)
+    const unsigned abort_seen = __hip_atomic_load(P()->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int T = p.team, cpcs = p.cpc_shift, cpc = 1 << cpcs;
     const int member = virt & (T - 1), team = virt / T;
     const int nteams = static_cast<int>(gridDim.x) / T;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
     int p_ko = 0, p_g = 0;
     float p_inv = 0.0f;
     draw(-1);
-    if (saw_dead) return;
+    if (saw_dead || abort_seen == P()->launch) return;
     if (d_valid) { land(); draw(-1); }                   // (the second ticket is transformed and published before the wave's first wait)
     for (;;) {
         if (saw_dead) leave();
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) __attribute__((amdgpu_num_vgpr(5
 #ifdef HSS_T16_BLKPROBE
     if (lane == 0 && virt < 256) {
         unsigned* e = g_t16_blk + (virt * 16 + wv) * 8;
-        e[0] = pb_miss; e[1] = 0u; e[2] = pb_blocked; e[3] = pb_fin; e[4] = pb_nfin;
+        e[0] = pb_miss; e[1] = pb_entry; e[7] = static_cast<unsigned>(wall_clock64()); e[2] = pb_blocked; e[3] = pb_fin; e[4] = pb_nfin;
         e[5] = static_cast<unsigned>(__builtin_readcyclecounter() - pb_c0); e[6] = static_cast<unsigned>(wall_clock64() - pb_r0);
     }
 #endif

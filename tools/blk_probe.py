@@ -27,3 +27,13 @@ for r in range(3):
     print(f"{os.path.basename(sys.argv[1])} {kind}: {e0.elapsed_time(e1) / K * 1e3:.1f} us per exec; last launch: misses {miss.sum() / 128000 * 100:.1f} % of the groups, "
           f"{blocked.sum() / max(miss.sum(), 1):.2f} us waited per miss = {blocked.mean():.2f} us per wave (p90 {np.percentile(blocked, 90):.2f}, max {blocked.max():.2f}); "
           f"resolvers take {fin.sum() / max(nfin.sum(), 1):.2f} us per signal = {fin.mean():.2f} us per wave; shader clock {100.0 * a[:, 5].sum() / max(a[:, 6].sum(), 1):.0f} MHz (cycle counter / 100 MHz clock over the waves' lifetimes: mean {a[:, 6].mean() / 100:.1f} us)")
+    ent, end = a[:, 1], a[:, 7]
+    t0 = ent.min()
+    ent, end = (ent - t0) / 100.0, (end - t0) / 100.0        # us since the first wave's first instruction
+    loop0 = end - a[:, 6] / 100.0                             # the wave's first draw (behind table staging and the block's barrier)
+    team_end = end.reshape(16, 256).max(axis=1)               # 16 teams x (16 CUs x 16 waves)
+    cu_end = end.reshape(256, 16).max(axis=1)
+    print(f"   timeline (us since the first wave entered): waves enter {ent.mean():.1f} +- {ent.std():.1f} (last {ent.max():.1f}); first draw {loop0.mean():.1f} (last {loop0.max():.1f}); "
+          f"waves end {end.mean():.1f} +- {end.std():.1f}, first {end.min():.1f}, last {end.max():.1f}; teams end {team_end.min():.1f} .. {team_end.max():.1f} (mean {team_end.mean():.1f}); "
+          f"CUs end mean {cu_end.mean():.1f}")
+    print("   teams end (us), in arrival order:", " ".join(f"{v:.1f}" for v in team_end), "| CUs of team 0 end:", " ".join(f"{v:.1f}" for v in cu_end[:16]))
