@@ -288,3 +288,39 @@ def test_shipped_code_object_keeps_the_fixed_registers():
         pytest.skip("no llvm-objdump")
     out = _lib.check_code_object()
     assert out["kernels"] >= 2 and out["metadata_checked"] >= 2 and out["accessor_instructions"] >= 100, out
+
+
+def test_lent_buffer_goes_back_when_the_last_view_dies():
+    """The drop-in call's result is a tensor over a pinned pool buffer the library LENT (hssfsst_exec_pinned): the ctypes array the tensor is made of
+    hands the buffer back from its ``__del__`` -- once, with the buffer's address, and only when the last view of the result is gone."""
+    import ctypes
+    import os
+
+    from heart_sounds_segmentation_amd.transforms import synchrosqueeze as sq
+
+    backing = np.arange(2000 * 44, dtype=np.float32)
+    released = []
+
+    class FakeL:
+        @staticmethod
+        def hssfsst_pinned_release(handle, ptr):
+            released.append(ptr.value)
+            return 0
+
+    class FakePlan:
+        handle = ctypes.c_void_p(1234)
+        pid = os.getpid()
+        _L = FakeL
+
+    buf = sq._lent_type(backing.size).from_address(backing.ctypes.data)
+    buf._plan = FakePlan
+    y = torch.from_numpy(np.frombuffer(buf, dtype=np.float32).reshape(2000, 44))
+    del buf
+    assert y.shape == (2000, 44) and float(y[1, 0]) == 44.0 and released == []
+    v = y[10:12]
+    del y
+    assert released == []                                # a view keeps the buffer on loan
+    assert float(v[0, 1]) == 441.0
+    del v
+    assert released == [backing.ctypes.data]
+    assert sq._lent_type(backing.size) is sq._lent_type(backing.size)      # one array type per result size
