@@ -11,6 +11,6 @@ timeout 600 python tools/share_curve.py 1 3 8 16 32 2>&1 | grep -v amdgpu > gpur
 for k in pcg zeros; do timeout 120 python tools/clock_watch.py heart_sounds_segmentation_amd/libhssfsst.so $k 3 2>&1 | grep -v amdgpu | tail -1 >> gpurun_out/r06g_power.txt; done
 timeout 300 python tools/flag_stress.py 30000 8 2>&1 | grep -v amdgpu | tail -3 > gpurun_out/r06g_flag_stress.txt
 timeout 200 python tools/call_breakdown.py 2>&1 | grep -v amdgpu > gpurun_out/r06g_call_breakdown.txt
-./devlibs/sync_latency > gpurun_out/r06g_sync_latency.txt 2>&1
+mkdir -p devlibs; [ -x devlibs/sync_latency ] || hipcc --offload-arch=gfx950 -O2 tools/sync_latency.hip -o devlibs/sync_latency > /dev/null 2>&1; ./devlibs/sync_latency > gpurun_out/r06g_sync_latency.txt 2>&1
 cat gpurun_out/r06g_gpu_pytest.txt
 tail -3 gpurun_out/r06g_adversarial_parity.txt; tail -3 gpurun_out/r06g_fuzz_parity.txt; tail -3 gpurun_out/r06g_split_fold_census.txt
